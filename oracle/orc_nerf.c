@@ -1,0 +1,376 @@
+/*
+ * orc_nerf.c -- CPU oracle (TEST INFRASTRUCTURE, see radnerf_oracle.h) for the
+ * PyTorch-level arithmetic of the path: NeRFNetwork.forward / density /
+ * forward_torso (nerf/network.py:188-325) and the inference branch of
+ * NeRFRenderer.run_cuda (nerf/renderer.py:158-204, 225-316), all in fp32.
+ *
+ * Third-party arithmetic restated here (PyTorch, pinned by the reference to
+ * "PyTorch 1.12 / CUDA 11.6", readme.md:15): nn.Linear(bias=False) = plain
+ * dot products; F.relu; torch.tanh; torch.sigmoid = 1/(1+exp(-x)); torch.exp;
+ * F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True)
+ * (ATen GridSampler: unnormalise ((c+1)/2)*(size-1), 4-tap bilinear, taps
+ * outside the image contribute 0).  Sums run in index order; the GPU path
+ * differs by summation order only (tolerances are stated in the tests).
+ */
+#include "radnerf_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+#define CHUNK 2048u
+#define MAX_W 160u /* widest activation row (torso_net input = 136) */
+
+/* nerf/network.py:69-88.  y[o] = sum_k x[k] * W[o][k], k ascending. */
+static void mlp_rows(const orc_mlp_t *mlp, const float *const *wt, const float *x, uint32_t B,
+                     uint32_t ldx, float *out, uint32_t ldo) {
+    float a[MAX_W], c[MAX_W];
+    for (uint32_t b = 0; b < B; b++) {
+        uint32_t din = mlp->dim_in;
+        memcpy(a, x + (size_t)b * ldx, din * sizeof(float));
+        for (uint32_t l = 0; l < mlp->num_layers; l++) {
+            const uint32_t dout = (l == mlp->num_layers - 1) ? mlp->dim_out : mlp->dim_hidden;
+            const float *w = wt[l]; /* transposed copy: [din][dout] */
+            for (uint32_t o = 0; o < dout; o++) c[o] = 0.0f;
+            for (uint32_t k = 0; k < din; k++) {
+                const float xk = a[k];
+                const float *wk = w + (size_t)k * dout;
+                for (uint32_t o = 0; o < dout; o++) c[o] += xk * wk[o];
+            }
+            if (l != mlp->num_layers - 1)
+                for (uint32_t o = 0; o < dout; o++) c[o] = c[o] > 0.0f ? c[o] : 0.0f;
+            memcpy(a, c, dout * sizeof(float));
+            din = dout;
+        }
+        memcpy(out + (size_t)b * ldo, a, mlp->dim_out * sizeof(float));
+    }
+}
+
+static void mlp_transpose(const orc_mlp_t *mlp, float **wt) {
+    uint32_t din = mlp->dim_in;
+    for (uint32_t l = 0; l < mlp->num_layers; l++) {
+        const uint32_t dout = (l == mlp->num_layers - 1) ? mlp->dim_out : mlp->dim_hidden;
+        wt[l] = (float *)malloc((size_t)din * dout * sizeof(float));
+        for (uint32_t o = 0; o < dout; o++)
+            for (uint32_t k = 0; k < din; k++) wt[l][(size_t)k * dout + o] = mlp->weights[l][(size_t)o * din + k];
+        din = dout;
+    }
+}
+static void mlp_free(const orc_mlp_t *mlp, float **wt) {
+    for (uint32_t l = 0; l < mlp->num_layers; l++) free(wt[l]);
+}
+
+void orc_mlp_forward(const orc_mlp_t *mlp, const float *x, uint32_t B, float *out) {
+    float *wt[4];
+    mlp_transpose(mlp, wt);
+#pragma omp parallel for schedule(static)
+    for (int64_t c0 = 0; c0 < (int64_t)B; c0 += CHUNK) {
+        const uint32_t n = (uint32_t)((int64_t)B - c0 < CHUNK ? (int64_t)B - c0 : CHUNK);
+        mlp_rows(mlp, (const float *const *)wt, x + (size_t)c0 * mlp->dim_in, n, mlp->dim_in,
+                 out + (size_t)c0 * mlp->dim_out, mlp->dim_out);
+    }
+    mlp_free(mlp, wt);
+}
+
+/* GridEncoder.forward (gridencoder/grid.py:145-161): (x + bound) / (2 * bound),
+ * kernel, then [L,B,C] -> [B, L*C]. */
+static void grid_apply(const orc_grid_t *g, const float *x, uint32_t ldx, uint32_t B, float bound,
+                       float *tmp_in, float *tmp_out, float *out, uint32_t ldo) {
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t d = 0; d < g->D; d++)
+            tmp_in[b * g->D + d] = (x[(size_t)b * ldx + d] + bound) / (2 * bound);
+    orc_grid_encode_forward(tmp_in, g->embeddings, g->offsets, tmp_out, B, g->D, g->C, g->L, g->S,
+                            g->H, NULL, g->gridtype, g->align_corners, g->interp, 0);
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t l = 0; l < g->L; l++)
+            for (uint32_t c = 0; c < g->C; c++)
+                out[(size_t)b * ldo + l * g->C + c] = tmp_out[((size_t)l * B + b) * g->C + c];
+}
+
+typedef struct {
+    float *wa[4], *ws[4], *wc[4];
+} nerf_wt_t;
+
+/* nerf/network.py:222-283 (density_only: :286-325) for one chunk */
+static void nerf_chunk(const orc_model_t *m, const nerf_wt_t *wt, const float *xyzs,
+                       const float *dirs, uint32_t n, const float *enc_a, const float *ind_code,
+                       const float *eye, float *sigma, float *color, float *ambient,
+                       int density_only) {
+    const uint32_t gx = m->enc_xyz.L * m->enc_xyz.C, gw = m->enc_ambient.L * m->enc_ambient.C;
+    const uint32_t A = m->audio_dim;
+    const uint32_t in_amb = gx + A, in_sig = gx + gw + (m->has_eye ? 1u : 0u);
+    const uint32_t geo = m->sigma_net.dim_out - 1;
+    const uint32_t nsh = m->sh_degree * m->sh_degree;
+    const uint32_t in_col = nsh + geo + m->ind_dim;
+
+    float *tin = (float *)malloc((size_t)n * 3 * sizeof(float));
+    float *tout = (float *)malloc((size_t)n * (gx > gw ? gx : gw) * sizeof(float));
+    float *h = (float *)malloc((size_t)n * MAX_W * sizeof(float));
+    float *amb = (float *)malloc((size_t)n * 2 * sizeof(float));
+    float *sg = (float *)malloc((size_t)n * m->sigma_net.dim_out * sizeof(float));
+    float *encx = (float *)malloc((size_t)n * gx * sizeof(float));
+
+    /* enc_x = self.encoder(x, bound=self.bound)  :240 */
+    grid_apply(&m->enc_xyz, xyzs, 3, n, m->bound, tin, tout, encx, gx);
+
+    /* ambient = tanh(ambient_net(cat[enc_x, enc_a]))  :245-247 */
+    for (uint32_t b = 0; b < n; b++) {
+        memcpy(h + (size_t)b * in_amb, encx + (size_t)b * gx, gx * sizeof(float));
+        memcpy(h + (size_t)b * in_amb + gx, enc_a, A * sizeof(float));
+    }
+    mlp_rows(&m->ambient_net, (const float *const *)wt->wa, h, n, in_amb, amb, 2);
+    for (uint32_t i = 0; i < n * 2; i++) amb[i] = tanhf(amb[i]);
+    if (ambient) memcpy(ambient, amb, (size_t)n * 2 * sizeof(float));
+
+    /* enc_w = self.encoder_ambient(ambient, bound=1)  :252 */
+    float *encw = tout + 0; /* reuse after permute below */
+    float *encw_perm = (float *)malloc((size_t)n * gw * sizeof(float));
+    grid_apply(&m->enc_ambient, amb, 2, n, 1.0f, tin, encw, encw_perm, gw);
+
+    /* h = cat[enc_x, enc_w, e]; h = sigma_net(h)  :257-261 */
+    for (uint32_t b = 0; b < n; b++) {
+        float *row = h + (size_t)b * in_sig;
+        memcpy(row, encx + (size_t)b * gx, gx * sizeof(float));
+        memcpy(row + gx, encw_perm + (size_t)b * gw, gw * sizeof(float));
+        if (m->has_eye) row[gx + gw] = eye[0];
+    }
+    mlp_rows(&m->sigma_net, (const float *const *)wt->ws, h, n, in_sig, sg, m->sigma_net.dim_out);
+
+    /* sigma = trunc_exp(h[..., 0])  :264, activation.py:5-11 */
+    for (uint32_t b = 0; b < n; b++) sigma[b] = expf(sg[(size_t)b * m->sigma_net.dim_out]);
+
+    if (!density_only) {
+        /* enc_d = self.encoder_dir(d); h = cat[enc_d, geo_feat, c]; color = sigmoid(color_net(h))  :268-281 */
+        float *encd = tout;
+        orc_sh_encode_forward(dirs, encd, n, 3, m->sh_degree, NULL);
+        for (uint32_t b = 0; b < n; b++) {
+            float *row = h + (size_t)b * in_col;
+            memcpy(row, encd + (size_t)b * nsh, nsh * sizeof(float));
+            memcpy(row + nsh, sg + (size_t)b * m->sigma_net.dim_out + 1, geo * sizeof(float));
+            if (m->ind_dim) memcpy(row + nsh + geo, ind_code, m->ind_dim * sizeof(float));
+        }
+        mlp_rows(&m->color_net, (const float *const *)wt->wc, h, n, in_col, color, 3);
+        for (uint32_t i = 0; i < n * 3; i++) color[i] = 1.0f / (1.0f + expf(-color[i]));
+    }
+    free(tin); free(tout); free(h); free(amb); free(sg); free(encx); free(encw_perm);
+}
+
+static void nerf_run(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
+                     const float *enc_a, const float *ind_code, const float *eye, float *sigma,
+                     float *color, float *ambient, int density_only) {
+    nerf_wt_t wt;
+    mlp_transpose(&m->ambient_net, wt.wa);
+    mlp_transpose(&m->sigma_net, wt.ws);
+    mlp_transpose(&m->color_net, wt.wc);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c0 = 0; c0 < (int64_t)M; c0 += CHUNK) {
+        const uint32_t n = (uint32_t)((int64_t)M - c0 < CHUNK ? (int64_t)M - c0 : CHUNK);
+        nerf_chunk(m, &wt, xyzs + (size_t)c0 * 3, dirs ? dirs + (size_t)c0 * 3 : NULL, n, enc_a,
+                   ind_code, eye, sigma + c0, color ? color + (size_t)c0 * 3 : NULL,
+                   ambient ? ambient + (size_t)c0 * 2 : NULL, density_only);
+    }
+    mlp_free(&m->ambient_net, wt.wa);
+    mlp_free(&m->sigma_net, wt.ws);
+    mlp_free(&m->color_net, wt.wc);
+}
+
+void orc_nerf_forward(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
+                      const float *enc_a, const float *ind_code, const float *eye,
+                      float *sigma, float *color, float *ambient) {
+    nerf_run(m, xyzs, dirs, M, enc_a, ind_code, eye, sigma, color, ambient, 0);
+}
+
+void orc_nerf_density(const orc_model_t *m, const float *xyzs, uint32_t M, const float *enc_a,
+                      const float *eye, float *sigma) {
+    nerf_run(m, xyzs, NULL, M, enc_a, NULL, eye, sigma, NULL, NULL, 1);
+}
+
+/* nerf/network.py:188-219 */
+void orc_torso_forward(const orc_model_t *m, const float *x, uint32_t P, const float *poses6,
+                       const float *ind_code_torso, float *alpha, float *color, float *dx) {
+    const uint32_t deg_x = 10, deg_p = 4;                 /* network.py:160-161 */
+    const uint32_t ex = 2 + 2 * 2 * deg_x, ep = 6 + 6 * 2 * deg_p; /* 42, 54 */
+    const uint32_t gt = m->enc_torso.L * m->enc_torso.C;
+    const uint32_t in_def = ex + ep + m->ind_dim_torso;   /* 104 */
+    const uint32_t in_tor = gt + in_def;                  /* 136 */
+    float *wd[4], *wtn[4];
+    mlp_transpose(&m->torso_deform_net, wd);
+    mlp_transpose(&m->torso_net, wtn);
+    float enc_pose[64];
+    orc_freq_encode_forward(poses6, 1, 6, deg_p, ep, enc_pose); /* :197 */
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c0 = 0; c0 < (int64_t)P; c0 += CHUNK) {
+        const uint32_t n = (uint32_t)((int64_t)P - c0 < CHUNK ? (int64_t)P - c0 : CHUNK);
+        float *xs = (float *)malloc((size_t)n * 2 * sizeof(float));
+        float *h = (float *)malloc((size_t)n * MAX_W * sizeof(float));
+        float *h2 = (float *)malloc((size_t)n * MAX_W * sizeof(float));
+        float *d2 = (float *)malloc((size_t)n * 2 * sizeof(float));
+        float *tin = (float *)malloc((size_t)n * 2 * sizeof(float));
+        float *tout = (float *)malloc((size_t)n * (gt > ex ? gt : ex) * sizeof(float));
+        float *o4 = (float *)malloc((size_t)n * 4 * sizeof(float));
+
+        for (uint32_t i = 0; i < n * 2; i++) xs[i] = x[(size_t)c0 * 2 + i] * m->torso_shrink; /* :194 */
+        orc_freq_encode_forward(xs, n, 2, deg_x, ex, tout);                                  /* :198 */
+        for (uint32_t b = 0; b < n; b++) {                                                   /* :201 */
+            float *row = h + (size_t)b * in_def;
+            memcpy(row, tout + (size_t)b * ex, ex * sizeof(float));
+            memcpy(row + ex, enc_pose, ep * sizeof(float));
+            if (m->ind_dim_torso) memcpy(row + ex + ep, ind_code_torso, m->ind_dim_torso * sizeof(float));
+        }
+        mlp_rows(&m->torso_deform_net, (const float *const *)wd, h, n, in_def, d2, 2);       /* :205 */
+        if (dx) memcpy(dx + (size_t)c0 * 2, d2, (size_t)n * 2 * sizeof(float));
+        for (uint32_t i = 0; i < n * 2; i++) {                                               /* :207 */
+            float v = xs[i] + d2[i];
+            xs[i] = fminf(fmaxf(v, -1.0f), 1.0f);
+        }
+        /* x = self.torso_encoder(x, bound=1); h = cat[x, h]  :209-212 */
+        float *enct = (float *)malloc((size_t)n * gt * sizeof(float));
+        grid_apply(&m->enc_torso, xs, 2, n, 1.0f, tin, tout, enct, gt);
+        for (uint32_t b = 0; b < n; b++) {
+            float *row = h2 + (size_t)b * in_tor;
+            memcpy(row, enct + (size_t)b * gt, gt * sizeof(float));
+            memcpy(row + gt, h + (size_t)b * in_def, in_def * sizeof(float));
+        }
+        mlp_rows(&m->torso_net, (const float *const *)wtn, h2, n, in_tor, o4, 4);            /* :214 */
+        for (uint32_t b = 0; b < n; b++) {                                                   /* :216-217 */
+            alpha[c0 + b] = 1.0f / (1.0f + expf(-o4[b * 4]));
+            for (uint32_t k = 0; k < 3; k++)
+                color[((size_t)c0 + b) * 3 + k] = 1.0f / (1.0f + expf(-o4[b * 4 + 1 + k]));
+        }
+        free(xs); free(h); free(h2); free(d2); free(tin); free(tout); free(o4); free(enct);
+    }
+    mlp_free(&m->torso_deform_net, wd);
+    mlp_free(&m->torso_net, wtn);
+}
+
+/* F.grid_sample(input[1,1,G,G], grid[(x,y)], bilinear, zeros, align_corners=True)
+ * as called at nerf/renderer.py:282 */
+static float grid_sample_2d(const float *img, uint32_t G, float gx, float gy) {
+    const float ix = ((gx + 1.f) / 2) * (float)(G - 1);
+    const float iy = ((gy + 1.f) / 2) * (float)(G - 1);
+    const float ix_nw = floorf(ix), iy_nw = floorf(iy);
+    const float ix_se = ix_nw + 1, iy_se = iy_nw + 1;
+    const float nw = (ix_se - ix) * (iy_se - iy), ne = (ix - ix_nw) * (iy_se - iy);
+    const float sw = (ix_se - ix) * (iy - iy_nw), se = (ix - ix_nw) * (iy - iy_nw);
+    const int64_t x0 = (int64_t)ix_nw, y0 = (int64_t)iy_nw, x1 = x0 + 1, y1 = y0 + 1;
+    const int64_t g = (int64_t)G;
+    float out = 0.0f;
+    if (x0 >= 0 && x0 < g && y0 >= 0 && y0 < g) out += img[y0 * g + x0] * nw;
+    if (x1 >= 0 && x1 < g && y0 >= 0 && y0 < g) out += img[y0 * g + x1] * ne;
+    if (x0 >= 0 && x0 < g && y1 >= 0 && y1 < g) out += img[y1 * g + x0] * sw;
+    if (x1 >= 0 && x1 < g && y1 >= 0 && y1 < g) out += img[y1 * g + x1] * se;
+    return out;
+}
+
+/* nerf/renderer.py:158-204 (setup), 225-262 (loop), 264-316 (torso, blend) */
+void orc_render_frame(const orc_model_t *m, const orc_render_cfg_t *cfg, const float *rays_o,
+                      const float *rays_d, uint32_t N, const float *enc_a,
+                      const float *ind_code, const float *eye, const float *bg_coords,
+                      const float *poses6, const float *ind_code_torso, const float *bg_color,
+                      float *image, float *depth, uint64_t *stats) {
+    float *nears = (float *)malloc((size_t)N * sizeof(float));
+    float *fars = (float *)malloc((size_t)N * sizeof(float));
+    float *weights_sum = (float *)calloc(N, sizeof(float));
+    float *rays_t = (float *)malloc((size_t)N * sizeof(float));
+    int32_t *rays_alive = (int32_t *)malloc((size_t)N * sizeof(int32_t));
+    uint64_t st_iter = 0, st_live = 0, st_slots = 0, st_torso = 0;
+
+    orc_near_far_from_aabb(rays_o, rays_d, cfg->aabb_infer, N, cfg->min_near, nears, fars); /* :183 */
+    memset(depth, 0, (size_t)N * sizeof(float));                                            /* :229-231 */
+    memset(image, 0, (size_t)N * 3 * sizeof(float));
+    uint32_t n_alive = N;
+    for (uint32_t i = 0; i < N; i++) rays_alive[i] = (int32_t)i;                             /* :234 */
+    memcpy(rays_t, nears, (size_t)N * sizeof(float));                                       /* :235 */
+
+    uint32_t step = 0;
+    while (step < cfg->max_steps) {                                                         /* :239 */
+        if (n_alive == 0) break;                                                            /* :245 */
+        uint32_t n_step = N / n_alive;                                                      /* :249 */
+        if (n_step > 8) n_step = 8;
+        if (n_step < 1) n_step = 1;
+        uint32_t M = n_alive * n_step;                 /* raymarching/raymarching.py:380-383 */
+        M += 128 - (M % 128);
+        float *xyzs = (float *)calloc((size_t)M * 3, sizeof(float));
+        float *dirs = (float *)calloc((size_t)M * 3, sizeof(float));
+        float *deltas = (float *)calloc((size_t)M * 2, sizeof(float));
+        float *noises = (float *)calloc(n_alive, sizeof(float));
+        float *sigmas = (float *)malloc((size_t)M * sizeof(float));
+        float *rgbs = (float *)malloc((size_t)M * 3 * sizeof(float));
+
+        orc_march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, cfg->bound,
+                       cfg->dt_gamma, cfg->max_steps, cfg->cascade, cfg->grid_size,
+                       cfg->density_bitfield, nears, fars, xyzs, dirs, deltas, noises);    /* :251 */
+        orc_nerf_forward(m, xyzs, dirs, M, enc_a, ind_code, eye, sigmas, rgbs, NULL);       /* :253 */
+        /* sigmas = self.density_scale * sigmas with density_scale = 1  :254 */
+        orc_composite_rays(n_alive, n_step, cfg->T_thresh, rays_alive, rays_t, sigmas, rgbs,
+                           deltas, weights_sum, depth, image);                              /* :256 */
+        for (uint32_t i = 0; i < M; i++) st_live += deltas[(size_t)i * 2] > 0.0f;
+        st_slots += M;
+        st_iter++;
+
+        uint32_t k = 0;                                  /* rays_alive[rays_alive >= 0]  :258 */
+        for (uint32_t i = 0; i < n_alive; i++)
+            if (rays_alive[i] >= 0) rays_alive[k++] = rays_alive[i];
+        n_alive = k;
+        step += n_step;                                                                     /* :262 */
+        free(xyzs); free(dirs); free(deltas); free(noises); free(sigmas); free(rgbs);
+    }
+
+    /* torso  :269-302 */
+    float *bg = (float *)malloc((size_t)N * 3 * sizeof(float));
+    memcpy(bg, bg_color, (size_t)N * 3 * sizeof(float));
+    if (cfg->torso) {
+        const float thresh = fminf(cfg->density_thresh_torso, cfg->mean_density_torso);     /* :281 */
+        uint32_t *idx = (uint32_t *)malloc((size_t)N * sizeof(uint32_t));
+        uint32_t P = 0;
+        for (uint32_t i = 0; i < N; i++) {
+            const float occ = grid_sample_2d(cfg->density_grid_torso, cfg->grid_size,
+                                             bg_coords[(size_t)i * 2], bg_coords[(size_t)i * 2 + 1]);
+            if (occ > thresh) idx[P++] = i;                                                  /* :283 */
+        }
+        st_torso = P;
+        if (P) {
+            float *xm = (float *)malloc((size_t)P * 2 * sizeof(float));
+            float *al = (float *)malloc((size_t)P * sizeof(float));
+            float *co = (float *)malloc((size_t)P * 3 * sizeof(float));
+            for (uint32_t p = 0; p < P; p++) {
+                xm[p * 2] = bg_coords[(size_t)idx[p] * 2];
+                xm[p * 2 + 1] = bg_coords[(size_t)idx[p] * 2 + 1];
+            }
+            orc_torso_forward(m, xm, P, poses6, ind_code_torso, al, co, NULL);               /* :290 */
+            /* bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)  :299
+             * (unmasked pixels have alpha = color = 0, which leaves bg_color unchanged) */
+            for (uint32_t p = 0; p < P; p++)
+                for (uint32_t k = 0; k < 3; k++) {
+                    const size_t o = (size_t)idx[p] * 3 + k;
+                    bg[o] = co[p * 3 + k] * al[p] + bg_color[o] * (1 - al[p]);
+                }
+            free(xm); free(al); free(co);
+        }
+        free(idx);
+    }
+
+    for (uint32_t i = 0; i < N; i++) {
+        for (uint32_t k = 0; k < 3; k++) {                                                  /* :306-308 */
+            float v = image[(size_t)i * 3 + k] + (1 - weights_sum[i]) * bg[(size_t)i * 3 + k];
+            image[(size_t)i * 3 + k] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+        const float dd = depth[i] - nears[i];                                               /* :310 */
+        depth[i] = (dd > 0.0f ? dd : 0.0f) / (fars[i] - nears[i]);
+    }
+    if (stats) { stats[0] = st_iter; stats[1] = st_live; stats[2] = st_slots; stats[3] = st_torso; }
+    free(nears); free(fars); free(weights_sum); free(rays_t); free(rays_alive); free(bg);
+}
