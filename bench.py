@@ -1,0 +1,187 @@
+"""Benchmark of the render hot path: frames/s at 512x512 (BASELINE.json config 1) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one full frame of NeRFRenderer.render: near/far, audio encoding (+ lip EMA), the <=16-step
+march / network / composite loop with early termination, the torso pass and the final blend -- on the
+synthetic scene of SURVEY §8(d) (ellipsoid head occupancy, OrbitCamera pose stream, random audio features,
+random-init weights), all inputs already resident in HBM.  Multi-GPU is frame-parallel: rank r renders
+frames r, r+N, ...; finished frames are quantised to uint8 on the device and gathered over RCCL; no other
+collective is on the data path (weak scaling: every rank renders K frames).
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event timed on
+its launch stream inside the timed region) and `cpu_baseline` (the oracle port of the same frame, timed on
+the host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rad-nerf_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--engine", default=os.environ.get("RN_ENGINE", "auto"), choices=["auto", "ops", "fused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
+    return ap.parse_args()
+
+
+def pick_engine(name):
+    if name != "auto":
+        return name
+    return "fused" if os.path.exists(os.path.join(ROOT, "rad-nerf_amd", "radnerf", "fused.py")) else "ops"
+
+
+# Algorithmic bytes per sample: xyz grid 16 levels x 8 corners x 8 B = 1024 B gathered
+# + 12 B of coordinates in + 128 B of features out.
+GRID_XYZ_BYTES_PER_SAMPLE = 1024 + 12 + 128
+
+
+def kernel_select(engine, acc):
+    """Which C-ABI call is the dominant kernel; accumulates its algorithmic bytes per launch into `acc`."""
+    if engine == "fused":
+        def sel(name, args):
+            return "nerf_fused" if name == "rn_nerf_forward_fused" else None
+        return sel
+
+    def sel(name, args):
+        # xyz grid lookup: D == 3 (args: inputs, table, offsets, outputs, B, D, C, L, ...)
+        if name == "rn_grid_encode_forward" and args[5] == 3:
+            acc["grid_encode_xyz"] = acc.get("grid_encode_xyz", 0.0) + float(args[4]) * GRID_XYZ_BYTES_PER_SAMPLE
+            return "grid_encode_xyz"
+        return None
+    return sel
+
+
+def cpu_baseline(scene_kwargs, size, opt_overrides):
+    """The oracle's port of the same frame (CPU, OpenMP over the host cores): bounded sample = 1 frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from radnerf.scene import SyntheticScene, default_opt
+    scene = SyntheticScene(H=size, W=size, n_frames=2, device="cpu", opt=default_opt(**opt_overrides), **scene_kwargs)
+    m = scene.model
+    f = scene.frame(0)
+    with torch.no_grad():
+        enc_a = m.encode_audio(f["auds"])
+    om = po.model_from_module(m)
+    rc = po.render_cfg_from_module(m, scene.opt.dt_gamma, scene.opt.max_steps)
+    args = (om, rc, f["rays_o"].numpy(), f["rays_d"].numpy(), enc_a.numpy(), m.individual_codes[0].detach().numpy(),
+            f["eye"].numpy(), f["bg_coords"].numpy(), f["poses"].numpy(), m.individual_codes_torso[0].detach().numpy(),
+            f["bg_color"].reshape(-1, 3).numpy())
+    po.render_frame(*args)  # warm-up (page-in, thread pool)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        _, _, stats = po.render_frame(*args)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 20:
+            break
+    return dict(value=reps / dt, unit="frames/s", cores=po.num_threads(), kind="port",
+                sample=f"{reps} x frame 0 of the same {size}x{size} workload through oracle/ (orc_render_frame, "
+                       f"fp32, OpenMP), {stats['live_samples']} samples/frame",
+                samples_per_s=stats["live_samples"] * reps / dt)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import radnerf_hip as hip
+    from radnerf.scene import SyntheticScene, default_opt
+    from radnerf.parallel import FrameParallelRenderer
+
+    engine = pick_engine(args.engine)
+    size = args.size
+    K, W = args.steps, args.warmup
+    n_frames = 250
+    scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device, opt=default_opt(engine=engine))
+    fpr = FrameParallelRenderer(scene, rank, world, dist)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for s in range(W):
+            fpr.step(s)
+        fpr.finish()
+        acc = {}
+        timer = hip.KernelTimer(kernel_select(engine, acc))
+        hip.set_timer(timer)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(W, W + K):
+            fpr.step(s)
+        fpr.finish()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        hip.set_timer(None)
+        # untimed replay of a few of the timed frames to count live samples per frame
+        live_pf, slots_pf = fpr.count_samples(list(range(W, W + min(K, 8))))
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    total_frames = K * world
+    fps = total_frames / elapsed
+
+    if rank == 0:
+        res = timer.results()
+        roof = None
+        for key, r in res.items():
+            per_launch_bytes = acc.get(key, 0.0) / max(r["launches"], 1)
+            achieved = per_launch_bytes / (r["avg_ms"] * 1e-3) / 1e9 if r["avg_ms"] > 0 else 0.0
+            roof = dict(bound="hbm", kernel=key, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=fpr.measured_traffic(key), launches=r["launches"],
+                        avg_launch_ms=r["avg_ms"], algorithmic_bytes_per_launch=per_launch_bytes,
+                        share_of_step=r["total_ms"] / (elapsed * 1e3))
+        out = {
+            "metric": "rendered frames/sec @512x512", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config[1]: single-GPU inference {size}x{size}, L=16 grids F=2 (tiled T=2^16 as the "
+                                   "shipped model), max 16 steps/ray, 25 FPS pose stream, torso pass on",
+                       "engine": engine, "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}"},
+            "samples_per_s": live_pf * fps, "samples_per_frame": live_pf, "sample_slots_per_frame": slots_pf,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb_size = args.cpu_baseline_size or size
+            out["cpu_baseline"] = cpu_baseline({}, cb_size, {})
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -462,3 +462,30 @@ def render_frame(model, rcfg, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, p
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def model_from_module(net):
+    """Build an oracle Model from a NeRFNetwork-like torch module (reference's or this tree's):
+    reads its state_dict (numpy copies) and the few scalar attributes the oracle needs."""
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    cfg = dict(per_level_scale_xyz=float(net.encoder.per_level_scale),
+               per_level_scale_ambient=float(net.encoder_ambient.per_level_scale),
+               base_resolution=int(net.encoder.base_resolution), gridtype=int(net.encoder.gridtype_id),
+               bound=float(net.bound), has_eye=bool(net.exp_eye), ind_dim=int(net.individual_dim),
+               audio_dim=int(net.audio_dim), sh_degree=int(net.encoder_dir.degree))
+    if getattr(net, "torso", False):
+        cfg.update(per_level_scale_torso=float(net.torso_encoder.per_level_scale),
+                   ind_dim_torso=int(net.individual_dim_torso), torso_shrink=float(net.opt.torso_shrink))
+    return Model(sd, cfg)
+
+
+def render_cfg_from_module(net, dt_gamma, max_steps, T_thresh=1e-4):
+    rc = dict(density_bitfield=net.density_bitfield.detach().cpu().numpy(), cascade=int(net.cascade),
+              grid_size=int(net.grid_size), bound=float(net.bound), min_near=float(net.min_near),
+              aabb_infer=net.aabb_infer.detach().cpu().numpy().tolist(), dt_gamma=float(dt_gamma),
+              max_steps=int(max_steps), T_thresh=float(T_thresh), torso=bool(net.torso))
+    if net.torso:
+        rc.update(density_grid_torso=net.density_grid_torso.detach().cpu().numpy(),
+                  density_thresh_torso=float(net.density_thresh_torso),
+                  mean_density_torso=float(net.mean_density_torso))
+    return rc

@@ -1,0 +1,22 @@
+"""trunc_exp with the reference's semantics (activation.py:5-17): exp forward in float32,
+backward g * exp(clamp(x, -15, 15))."""
+import torch
+from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
+
+
+class _trunc_exp(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x = ctx.saved_tensors[0]
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _trunc_exp.apply

@@ -1,0 +1,597 @@
+// rn_grid.hip -- multiresolution hash / tiled grid encoder for gfx950.
+//
+// Behaviour follows gridencoder/src/gridencoder.cu of the reference (cited per kernel).
+// MI355X-first choices:
+//   * per-level constants (scale, resolution) are computed once on the HOST with the same libm
+//     exp2f the CPU oracle uses and travel as kernel arguments, so the lattice position -- and with
+//     it every integer table index -- is bit-identical to the oracle (-ffp-contract=off keeps
+//     x*scale+0.5 unfused);
+//   * a feature row (C scalars) is fetched with ONE load of C*sizeof(T) bytes;
+//   * two work decompositions: level-major (one (sample, level) per lane, reference layout
+//     [L,B,C], only one level's table is live in an XCD's L2 at a time) and sample-major (one
+//     sample per lane walks all levels and stores its whole [L*C] row, layout [B, L*C], which
+//     removes the reference's permute copy).
+#include "rn_common.h"
+
+#include <math.h>
+
+namespace rn {
+
+constexpr uint32_t kMaxLevels = 32;
+
+struct LevelConsts {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+static LevelConsts make_level_consts(uint32_t L, float S, uint32_t H) {
+    LevelConsts lc{};
+    for (uint32_t l = 0; l < L; l++) {
+        // gridencoder.cu:138-139
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;
+        lc.scale[l] = scale;
+        lc.resolution[l] = (uint32_t)ceilf(scale) + 1;
+    }
+    return lc;
+}
+
+// ---- scalar helpers ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half_rn(v); }
+
+// One aligned load / store of a C-wide feature row.
+template <typename T, uint32_t C>
+__device__ __forceinline__ void load_row(const T *p, T (&v)[C]) {
+    constexpr uint32_t bytes = sizeof(T) * C;
+    if constexpr (bytes == 2) { *reinterpret_cast<uint16_t *>(v) = *reinterpret_cast<const uint16_t *>(p); }
+    else if constexpr (bytes == 4) { *reinterpret_cast<uint32_t *>(v) = *reinterpret_cast<const uint32_t *>(p); }
+    else if constexpr (bytes == 8) { *reinterpret_cast<uint2 *>(v) = *reinterpret_cast<const uint2 *>(p); }
+    else if constexpr (bytes == 16) { *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(p); }
+    else {
+        static_assert(bytes == 32, "unsupported row width");
+        reinterpret_cast<uint4 *>(v)[0] = reinterpret_cast<const uint4 *>(p)[0];
+        reinterpret_cast<uint4 *>(v)[1] = reinterpret_cast<const uint4 *>(p)[1];
+    }
+}
+template <typename T, uint32_t C>
+__device__ __forceinline__ void store_row(T *p, const T (&v)[C]) {
+    constexpr uint32_t bytes = sizeof(T) * C;
+    if constexpr (bytes == 2) { *reinterpret_cast<uint16_t *>(p) = *reinterpret_cast<const uint16_t *>(v); }
+    else if constexpr (bytes == 4) { *reinterpret_cast<uint32_t *>(p) = *reinterpret_cast<const uint32_t *>(v); }
+    else if constexpr (bytes == 8) { *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(v); }
+    else if constexpr (bytes == 16) { *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(v); }
+    else {
+        static_assert(bytes == 32, "unsupported row width");
+        reinterpret_cast<uint4 *>(p)[0] = reinterpret_cast<const uint4 *>(v)[0];
+        reinterpret_cast<uint4 *>(p)[1] = reinterpret_cast<const uint4 *>(v)[1];
+    }
+}
+
+// gridencoder.cu:50-63
+template <uint32_t D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t (&pos_grid)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t result = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+    return result;
+}
+
+// Row index of a lattice corner (gridencoder.cu:66-84 without the "* C + ch").
+template <uint32_t D>
+__device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
+                                             uint32_t resolution, const uint32_t (&pos_grid)[D]) {
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pos_grid[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
+    return index % hashmap_size;
+}
+
+__device__ __forceinline__ float smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
+__device__ __forceinline__ float smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
+
+// Lattice position of one sample at one level (gridencoder.cu:146-158). Returns false when out of [0,1].
+template <uint32_t D>
+__device__ __forceinline__ void lattice_pos(const float (&in)[D], float scale, bool align_corners, uint32_t interp,
+                                            float (&pos)[D], float (&pos_deriv)[D], uint32_t (&pos_grid)[D]) {
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = in[d] * scale + (align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) {
+            pos_deriv[d] = smoothstep_derivative(pos[d]);
+            pos[d] = smoothstep(pos[d]);
+        } else {
+            pos_deriv[d] = 1.0f;
+        }
+    }
+}
+
+// Interpolated features (and optionally d/dx) of one sample at one level.
+// `grid` already points at the level's first row.  Accumulation follows the reference's
+// scalar_t semantics: results live in T and every += rounds to T (gridencoder.cu:163,186,234).
+template <typename T, uint32_t D, uint32_t C, bool DYDX>
+__device__ __forceinline__ void encode_level(const T *__restrict__ grid, const float (&in)[D], float scale,
+                                             uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
+                                             bool align_corners, uint32_t interp, T (&results)[C],
+                                             T (&grads)[DYDX ? D * C : 1]) {
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+    lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
+
+    // issue all 2^D row loads first, then blend
+    T rows[1 << D][C];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
+        const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        load_row<T, C>(grid + (size_t)row * C, rows[idx]);
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(to_f<T>(results[ch]) + w * to_f<T>(rows[idx][ch]));
+    }
+
+    if constexpr (DYDX) {
+        // gridencoder.cu:200-243; corner `idx` of the (D-1)-face with bit gd cleared / set
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            T rg[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] = from_f<T>(0.0f);
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t corner = 0;  // index into rows[] of the "left" corner
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    const bool hi = (idx >> nd) & 1u;
+                    w *= hi ? pos[d] : 1 - pos[d];
+                    corner |= hi ? (1u << d) : 0u;
+                }
+                const uint32_t left = corner, right = corner | (1u << gd);
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float diff = to_f<T>(from_f<T>(to_f<T>(rows[right][ch]) - to_f<T>(rows[left][ch])));
+                    rg[ch] = from_f<T>(to_f<T>(rg[ch]) + w * diff * pos_deriv[gd]);
+                }
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) grads[gd * C + ch] = rg[ch];
+        }
+    }
+}
+
+template <uint32_t D>
+__device__ __forceinline__ bool load_input(const float *__restrict__ inputs, uint32_t b, float (&in)[D]) {
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        oob |= (in[d] < 0 || in[d] > 1);  // gridencoder.cu:113-117
+    }
+    return oob;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level-major forward (gridencoder.cu:87-244): grid = (ceil(B/256), L).
+template <typename T, uint32_t D, uint32_t C, bool DYDX, int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_fwd_level(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
+                 T *__restrict__ outputs, uint32_t B, uint32_t L, LevelConsts lc, T *__restrict__ dy_dx,
+                 uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+
+    float in[D];
+    const bool oob = load_input<D>(inputs, b, in);
+
+    T results[C];
+    T grads[DYDX ? D * C : 1];
+    if (oob) {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);
+        if constexpr (DYDX) {
+#pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) grads[i] = from_f<T>(0.0f);
+        }
+    } else {
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+        encode_level<T, D, C, DYDX>(table + (size_t)off * C, in, lc.scale[level], lc.resolution[level], hashmap_size,
+                                    gridtype, align_corners, interp, results, grads);
+    }
+    T *o = (LAYOUT == RN_LAYOUT_LBC) ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;
+    store_row<T, C>(o, results);
+    if constexpr (DYDX) {
+        T *g = dy_dx + ((size_t)b * L + level) * D * C;  // [B, L, D, C]
+#pragma unroll
+        for (uint32_t i = 0; i < D * C; i++) g[i] = grads[i];
+    }
+}
+
+// Sample-major forward: one sample per lane walks every level, [B, L*C] rows.
+template <typename T, uint32_t D, uint32_t C, bool DYDX, int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_fwd_sample(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
+                  T *__restrict__ outputs, uint32_t B, uint32_t L, LevelConsts lc, T *__restrict__ dy_dx,
+                  uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float in[D];
+    const bool oob = load_input<D>(inputs, b, in);
+    uint32_t off = (uint32_t)offsets[0];
+    for (uint32_t level = 0; level < L; level++) {
+        const uint32_t next = (uint32_t)offsets[level + 1];
+        T results[C];
+        T grads[DYDX ? D * C : 1];
+        if (oob) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);
+            if constexpr (DYDX) {
+#pragma unroll
+                for (uint32_t i = 0; i < D * C; i++) grads[i] = from_f<T>(0.0f);
+            }
+        } else {
+            encode_level<T, D, C, DYDX>(table + (size_t)off * C, in, lc.scale[level], lc.resolution[level], next - off,
+                                        gridtype, align_corners, interp, results, grads);
+        }
+        T *o = (LAYOUT == RN_LAYOUT_LBC) ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;
+        store_row<T, C>(o, results);
+        if constexpr (DYDX) {
+            T *g = dy_dx + ((size_t)b * L + level) * D * C;
+#pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) g[i] = grads[i];
+        }
+        off = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward to the table (gridencoder.cu:247-339): one (sample, level, channel pair) per lane.
+__device__ __forceinline__ void atomic_add_row(float *p, const float (&v)[1]) { atomicAdd(p, v[0]); }
+__device__ __forceinline__ void atomic_add_row(float *p, const float (&v)[2]) { atomicAdd(p, v[0]); atomicAdd(p + 1, v[1]); }
+__device__ __forceinline__ void atomic_add_row(__half *p, const float (&v)[1]) {
+    // C == 1 in half: emulate with a 32-bit CAS on the containing word (the reference never takes this path fast either)
+    uint32_t *w = reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(3));
+    const bool hi = reinterpret_cast<uintptr_t>(p) & 2;
+    uint32_t old = *w, assumed;
+    do {
+        assumed = old;
+        const uint16_t cur = hi ? (uint16_t)(assumed >> 16) : (uint16_t)(assumed & 0xffffu);
+        const __half sum = __float2half_rn(__half2float(__ushort_as_half(cur)) + __half2float(__float2half_rn(v[0])));
+        const uint32_t nw = hi ? ((assumed & 0x0000ffffu) | ((uint32_t)__half_as_ushort(sum) << 16))
+                               : ((assumed & 0xffff0000u) | (uint32_t)__half_as_ushort(sum));
+        old = atomicCAS(w, assumed, nw);
+    } while (old != assumed);
+}
+__device__ __forceinline__ void atomic_add_row(__half *p, const float (&v)[2]) {
+    // packed half2 atomic (gridencoder.cu:324-330) -> global_atomic_pk_add_f16
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    half2_t x;
+    x[0] = (_Float16)v[0];
+    x[1] = (_Float16)v[1];
+    typedef __attribute__((address_space(1))) half2_t *gptr_t;
+    __builtin_amdgcn_global_atomic_fadd_v2f16((gptr_t)(p), x);
+}
+
+template <typename T, uint32_t D, uint32_t C, uint32_t N_C, int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_bwd_table(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                 T *__restrict__ grad_grid, uint32_t B, uint32_t L, LevelConsts lc, uint32_t gridtype,
+                 bool align_corners, uint32_t interp) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b = tid * N_C / C;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t ch = tid * N_C - b * C;
+
+    float in[D];
+    if (load_input<D>(inputs, b, in)) return;  // grad table is zero-initialised (gridencoder.cu:275-280)
+
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const float scale = lc.scale[level];
+    const uint32_t resolution = lc.resolution[level];
+
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+    lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
+
+    const T *g = (LAYOUT == RN_LAYOUT_LBC) ? grad + ((size_t)level * B + b) * C + ch : grad + ((size_t)b * L + level) * C + ch;
+    T gc[N_C];
+    load_row<T, N_C>(g, gc);
+    float grad_cur[N_C];
+#pragma unroll
+    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = to_f<T>(gc[c]);
+
+    T *gg = grad_grid + (size_t)off * C + ch;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const bool hi = (idx >> d) & 1u;
+            w *= hi ? pos[d] : 1 - pos[d];
+            pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
+        }
+        const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        float v[N_C];
+#pragma unroll
+        for (uint32_t c = 0; c < N_C; c++) v[c] = w * grad_cur[c];
+        atomic_add_row(gg + (size_t)row * C, v);
+    }
+}
+
+// Backward to the inputs (gridencoder.cu:342-368): grad_inputs[b,d] = sum_{l,ch} grad * dy_dx.
+template <typename T, uint32_t D, uint32_t C, int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_bwd_input(const T *__restrict__ grad, const T *__restrict__ dy_dx, T *__restrict__ grad_inputs, uint32_t B,
+                 uint32_t L) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T *dd = dy_dx + (size_t)b * L * D * C;
+    T result = from_f<T>(0.0f);
+    for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const T gv = (LAYOUT == RN_LAYOUT_LBC) ? grad[((size_t)l * B + b) * C + ch] : grad[((size_t)b * L + l) * C + ch];
+            const T prod = from_f<T>(to_f<T>(gv) * to_f<T>(dd[(size_t)l * D * C + d * C + ch]));
+            result = from_f<T>(to_f<T>(result) + to_f<T>(prod));
+        }
+    }
+    grad_inputs[t] = result;
+}
+
+// Total-variation gradient (gridencoder.cu:505-609), float32.
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256)
+k_grad_tv(const float *__restrict__ inputs, const float *__restrict__ table, float *__restrict__ grad,
+          const int32_t *__restrict__ offsets, float weight, uint32_t B, LevelConsts lc, uint32_t gridtype,
+          bool align_corners) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    float in[D];
+    if (load_input<D>(inputs, b, in)) return;
+
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const float scale = lc.scale[level];
+    const uint32_t resolution = lc.resolution[level];
+    const float *grid = table + (size_t)off * C;
+    float *gr = grad + (size_t)off * C;
+
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) pos_grid[d] = (uint32_t)floorf(in[d] * scale + (align_corners ? 0.0f : 0.5f));
+
+    float results[C], idelta[C], center[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) { results[ch] = 0; idelta[ch] = 0; }
+    const uint32_t index = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C;
+    load_row<float, C>(grid + index, center);
+    const float w = weight / (float)(2 * D);
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t cur_d = pos_grid[d];
+        if (cur_d < resolution) {
+            pos_grid[d] = cur_d + 1;
+            float nb[C];
+            load_row<float, C>(grid + grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C, nb);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) { const float gv = center[ch] - nb[ch]; results[ch] += gv; idelta[ch] += gv * gv; }
+        }
+        if (cur_d > 0) {
+            pos_grid[d] = cur_d - 1;
+            float nb[C];
+            load_row<float, C>(grid + grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C, nb);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) { const float gv = center[ch] - nb[ch]; results[ch] += gv; idelta[ch] += gv * gv; }
+        }
+        pos_grid[d] = cur_d;
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) atomicAdd(&gr[index + ch], w * results[ch] * (1.0f / sqrtf(idelta[ch] + 1e-9f)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+struct FwdArgs {
+    const float *inputs; const void *table; const int32_t *offsets; void *outputs; uint32_t B, L; LevelConsts lc;
+    void *dy_dx; uint32_t gridtype; bool align_corners; uint32_t interp; int layout; hipStream_t stream;
+};
+
+template <typename T, uint32_t D, uint32_t C>
+static void launch_fwd(const FwdArgs &a) {
+    const T *table = static_cast<const T *>(a.table);
+    T *out = static_cast<T *>(a.outputs);
+    T *dy = static_cast<T *>(a.dy_dx);
+    const dim3 block(256);
+#define RN_FWD(KERNEL, GRID, DY, LAY)                                                                              \
+    hipLaunchKernelGGL((KERNEL<T, D, C, DY, LAY>), GRID, block, 0, a.stream, a.inputs, table, a.offsets, out, a.B, \
+                       a.L, a.lc, dy, a.gridtype, a.align_corners, a.interp)
+    if (a.layout == RN_LAYOUT_LBC) {
+        const dim3 grid(div_up(a.B, 256), a.L);
+        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_LBC); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_LBC);
+    } else {
+        const dim3 grid(div_up(a.B, 256));
+        if (dy) RN_FWD(k_grid_fwd_sample, grid, true, RN_LAYOUT_BLC); else RN_FWD(k_grid_fwd_sample, grid, false, RN_LAYOUT_BLC);
+    }
+#undef RN_FWD
+}
+
+template <typename T, uint32_t D>
+static int dispatch_fwd_c(uint32_t C, const FwdArgs &a) {
+    switch (C) {
+        case 1: launch_fwd<T, D, 1>(a); return RN_OK;
+        case 2: launch_fwd<T, D, 2>(a); return RN_OK;
+        case 4: launch_fwd<T, D, 4>(a); return RN_OK;
+        case 8: launch_fwd<T, D, 8>(a); return RN_OK;
+    }
+    set_error("GridEncoding: C must be 1, 2, 4, or 8.");  // gridencoder.cu:380
+    return RN_ERR_INVALID_ARG;
+}
+template <typename T>
+static int dispatch_fwd_d(uint32_t D, uint32_t C, const FwdArgs &a) {
+    switch (D) {
+        case 2: return dispatch_fwd_c<T, 2>(C, a);
+        case 3: return dispatch_fwd_c<T, 3>(C, a);
+        case 4: return dispatch_fwd_c<T, 4>(C, a);
+        case 5: return dispatch_fwd_c<T, 5>(C, a);
+    }
+    set_error("GridEncoding: D must be 2, 3, 4 or 5.");  // gridencoder.cu:397
+    return RN_ERR_INVALID_ARG;
+}
+
+struct BwdArgs {
+    const void *grad; const float *inputs; const int32_t *offsets; void *grad_table; uint32_t B, L; LevelConsts lc;
+    const void *dy_dx; void *grad_inputs; uint32_t gridtype; bool align_corners; uint32_t interp; int layout;
+    hipStream_t stream;
+};
+
+template <typename T, uint32_t D, uint32_t C>
+static void launch_bwd(const BwdArgs &a) {
+    constexpr uint32_t N_C = C < 2 ? C : 2;  // gridencoder.cu:404
+    const T *grad = static_cast<const T *>(a.grad);
+    T *gt = static_cast<T *>(a.grad_table);
+    const dim3 block(256), grid(div_up(a.B * C / N_C, 256), a.L);
+    if (a.layout == RN_LAYOUT_LBC)
+        hipLaunchKernelGGL((k_grid_bwd_table<T, D, C, N_C, RN_LAYOUT_LBC>), grid, block, 0, a.stream, grad, a.inputs,
+                           a.offsets, gt, a.B, a.L, a.lc, a.gridtype, a.align_corners, a.interp);
+    else
+        hipLaunchKernelGGL((k_grid_bwd_table<T, D, C, N_C, RN_LAYOUT_BLC>), grid, block, 0, a.stream, grad, a.inputs,
+                           a.offsets, gt, a.B, a.L, a.lc, a.gridtype, a.align_corners, a.interp);
+    if (a.dy_dx && a.grad_inputs) {
+        const T *dy = static_cast<const T *>(a.dy_dx);
+        T *gi = static_cast<T *>(a.grad_inputs);
+        const dim3 g2(div_up(a.B * D, 256));
+        if (a.layout == RN_LAYOUT_LBC)
+            hipLaunchKernelGGL((k_grid_bwd_input<T, D, C, RN_LAYOUT_LBC>), g2, block, 0, a.stream, grad, dy, gi, a.B, a.L);
+        else
+            hipLaunchKernelGGL((k_grid_bwd_input<T, D, C, RN_LAYOUT_BLC>), g2, block, 0, a.stream, grad, dy, gi, a.B, a.L);
+    }
+}
+template <typename T, uint32_t D>
+static int dispatch_bwd_c(uint32_t C, const BwdArgs &a) {
+    switch (C) {
+        case 1: launch_bwd<T, D, 1>(a); return RN_OK;
+        case 2: launch_bwd<T, D, 2>(a); return RN_OK;
+        case 4: launch_bwd<T, D, 4>(a); return RN_OK;
+        case 8: launch_bwd<T, D, 8>(a); return RN_OK;
+    }
+    set_error("GridEncoding: C must be 1, 2, 4, or 8.");
+    return RN_ERR_INVALID_ARG;
+}
+template <typename T>
+static int dispatch_bwd_d(uint32_t D, uint32_t C, const BwdArgs &a) {
+    switch (D) {
+        case 2: return dispatch_bwd_c<T, 2>(C, a);
+        case 3: return dispatch_bwd_c<T, 3>(C, a);
+        case 4: return dispatch_bwd_c<T, 4>(C, a);
+        case 5: return dispatch_bwd_c<T, 5>(C, a);
+    }
+    set_error("GridEncoding: D must be 2, 3, 4 or 5.");
+    return RN_ERR_INVALID_ARG;
+}
+
+template <uint32_t D>
+static int dispatch_tv_c(uint32_t C, const float *inputs, const float *table, float *grad, const int32_t *offsets,
+                         float weight, uint32_t B, uint32_t L, const LevelConsts &lc, uint32_t gridtype, bool ac,
+                         hipStream_t s) {
+    const dim3 block(256), grid(div_up(B, 256), L);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grad_tv<D, 1>), grid, block, 0, s, inputs, table, grad, offsets, weight, B, lc, gridtype, ac); return RN_OK;
+        case 2: hipLaunchKernelGGL((k_grad_tv<D, 2>), grid, block, 0, s, inputs, table, grad, offsets, weight, B, lc, gridtype, ac); return RN_OK;
+        case 4: hipLaunchKernelGGL((k_grad_tv<D, 4>), grid, block, 0, s, inputs, table, grad, offsets, weight, B, lc, gridtype, ac); return RN_OK;
+        case 8: hipLaunchKernelGGL((k_grad_tv<D, 8>), grid, block, 0, s, inputs, table, grad, offsets, weight, B, lc, gridtype, ac); return RN_OK;
+    }
+    set_error("GridEncoding: C must be 1, 2, 4, or 8.");
+    return RN_ERR_INVALID_ARG;
+}
+
+}  // namespace rn
+
+using namespace rn;
+
+extern "C" {
+
+int rn_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs,
+                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
+                           uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int layout,
+                           rn_stream_t stream) {
+    RN_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
+    RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L=%u out of range (1..%u)", L, kMaxLevels);
+    RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_forward: dtype must be RN_F32 or RN_F16");
+    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_forward: bad layout");
+    RN_REQUIRE(gridtype <= 1 && interp <= 1, "grid_encode_forward: bad gridtype / interpolation id");
+    if (B == 0) return RN_OK;
+    FwdArgs a{inputs, embeddings, offsets, outputs, B, L, make_level_consts(L, S, H), dy_dx, gridtype,
+              align_corners != 0, interp, layout, as_stream(stream)};
+    const int rc = (dtype == RN_F32) ? dispatch_fwd_d<float>(D, C, a) : dispatch_fwd_d<__half>(D, C, a);
+    if (rc != RN_OK) return rc;
+    return check_launch("grid_encode_forward");
+}
+
+int rn_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
+                            void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                            uint32_t H, const void *dy_dx, void *grad_inputs, uint32_t gridtype, int align_corners,
+                            uint32_t interp, int dtype, int layout, rn_stream_t stream) {
+    (void)embeddings;
+    RN_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
+    RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L=%u out of range (1..%u)", L, kMaxLevels);
+    RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_backward: dtype must be RN_F32 or RN_F16");
+    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_backward: bad layout");
+    RN_REQUIRE(gridtype <= 1 && interp <= 1, "grid_encode_backward: bad gridtype / interpolation id");
+    if (B == 0) return RN_OK;
+    BwdArgs a{grad, inputs, offsets, grad_embeddings, B, L, make_level_consts(L, S, H), dy_dx, grad_inputs, gridtype,
+              align_corners != 0, interp, layout, as_stream(stream)};
+    const int rc = (dtype == RN_F32) ? dispatch_bwd_d<float>(D, C, a) : dispatch_bwd_d<__half>(D, C, a);
+    if (rc != RN_OK) return rc;
+    return check_launch("grid_encode_backward");
+}
+
+int rn_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets,
+                            float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            uint32_t gridtype, int align_corners, rn_stream_t stream) {
+    RN_REQUIRE(inputs && embeddings && grad && offsets, "grad_total_variation: null pointer");
+    RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grad_total_variation: L=%u out of range (1..%u)", L, kMaxLevels);
+    if (B == 0) return RN_OK;
+    const LevelConsts lc = make_level_consts(L, S, H);
+    int rc;
+    switch (D) {
+        case 2: rc = dispatch_tv_c<2>(C, inputs, embeddings, grad, offsets, weight, B, L, lc, gridtype, align_corners != 0, as_stream(stream)); break;
+        case 3: rc = dispatch_tv_c<3>(C, inputs, embeddings, grad, offsets, weight, B, L, lc, gridtype, align_corners != 0, as_stream(stream)); break;
+        case 4: rc = dispatch_tv_c<4>(C, inputs, embeddings, grad, offsets, weight, B, L, lc, gridtype, align_corners != 0, as_stream(stream)); break;
+        case 5: rc = dispatch_tv_c<5>(C, inputs, embeddings, grad, offsets, weight, B, L, lc, gridtype, align_corners != 0, as_stream(stream)); break;
+        default: set_error("GridEncoding: D must be 2, 3, 4 or 5."); return RN_ERR_INVALID_ARG;
+    }
+    if (rc != RN_OK) return rc;
+    return check_launch("grad_total_variation");
+}
+
+}  // extern "C"

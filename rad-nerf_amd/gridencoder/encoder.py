@@ -1,0 +1,187 @@
+"""Multiresolution hash / tiled grid encoder over libradnerf_hip.so.
+
+Public surface of the reference's gridencoder/grid.py: `grid_encode` (autograd Function) and
+`GridEncoder(nn.Module)` with the same constructor arguments, `.embeddings` / `.offsets` state-dict
+entries, `.forward(inputs, bound=1)` and `.grad_total_variation(...)`.
+
+What changed underneath: the kernel writes [B, L*C] directly (no permute copy, grid.py:57,75);
+under autocast the half table is cached between calls instead of being re-cast per call
+(grid.py:43-44 re-casts 7 MB per loop iteration); kernels run on the current stream.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
+
+import radnerf_hip as hip
+
+_gridtype_to_id = {"hash": 0, "tiled": 1}
+_interp_to_id = {"linear": 0, "smoothstep": 1}
+
+
+def _dtype_id(t):
+    if t.dtype == torch.float32:
+        return hip.RN_F32
+    if t.dtype == torch.float16:
+        return hip.RN_F16
+    raise RuntimeError(f"grid_encode: embeddings must be float32 or float16, got {t.dtype}")
+
+
+def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners):
+    """Row offsets of the per-level tables (gridencoder/grid.py:118-129)."""
+    offsets, offset = [], 0
+    max_params = 2 ** log2_hashmap_size
+    for i in range(num_levels):
+        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+        params_in_level = min(max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+        params_in_level = int(np.ceil(params_in_level / 8) * 8)
+        offsets.append(offset)
+        offset += params_in_level
+    offsets.append(offset)
+    return np.array(offsets, dtype=np.int32)
+
+
+class _grid_encode(Function):
+    # gridencoder/grid.py:24-89
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
+                gridtype=0, align_corners=False, interpolation=0, half_table=None):
+        inputs = hip.dev(inputs).contiguous()
+        if inputs.dtype != torch.float32:
+            inputs = inputs.float()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+
+        # autocast: half table when C is even (grid.py:41-44); inputs stay float32
+        if torch.is_autocast_enabled("cuda") and C % 2 == 0:
+            table = half_table if half_table is not None else embeddings.to(torch.half)
+        else:
+            table = embeddings
+        table = hip.aligned(table)
+
+        outputs = torch.empty(B, L * C, device=inputs.device, dtype=table.dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=table.dtype) if calc_grad_inputs else None
+
+        hip.call("rn_grid_encode_forward", hip.ptr(inputs), hip.ptr(table), hip.ptr(offsets, torch.int32),
+                 hip.ptr(outputs), B, D, C, L, S, H, hip.ptr(dy_dx), int(gridtype), int(bool(align_corners)),
+                 int(interpolation), _dtype_id(table), hip.RN_LAYOUT_BLC, hip.stream())
+
+        ctx.save_for_backward(inputs, table, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, H, gridtype, interpolation)
+        ctx.align_corners = align_corners
+        ctx.emb_dtype = embeddings.dtype
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, table, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+        grad = hip.aligned(grad.to(table.dtype))  # [B, L*C], read in place by the kernel
+
+        grad_embeddings = torch.zeros_like(table)
+        grad_inputs = torch.zeros(B, D, device=inputs.device, dtype=table.dtype) if dy_dx is not None else None
+
+        hip.call("rn_grid_encode_backward", hip.ptr(grad), hip.ptr(inputs), hip.ptr(table),
+                 hip.ptr(offsets, torch.int32), hip.ptr(grad_embeddings), B, D, C, L, S, H, hip.ptr(dy_dx),
+                 hip.ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)), int(interpolation),
+                 _dtype_id(table), hip.RN_LAYOUT_BLC, hip.stream())
+
+        if grad_inputs is not None:
+            grad_inputs = grad_inputs.to(inputs.dtype)
+        grad_embeddings = grad_embeddings.to(ctx.emb_dtype)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    # gridencoder/grid.py:96-184
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None, gridtype="hash", align_corners=False,
+                 interpolation="linear"):
+        super().__init__()
+        # the finest resolution, when given, overrides per_level_scale (grid.py:101-102)
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _interp_to_id[interpolation]
+        self.align_corners = align_corners
+        self.max_params = 2 ** log2_hashmap_size
+
+        offsets = level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size,
+                                align_corners)
+        self.register_buffer("offsets", torch.from_numpy(offsets))
+        self.n_params = int(offsets[-1]) * level_dim
+        self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
+        self.reset_parameters()
+        self._half = None  # (version, data_ptr, tensor) cache of the fp16 table used under autocast
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> "
+                f"{int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} "
+                f"gridtype={self.gridtype} align_corners={self.align_corners} interpolation={self.interpolation}")
+
+    def half_table(self):
+        """fp16 copy of the table, rebuilt only when the parameter changed (in-place version counter)."""
+        e = self.embeddings
+        key = (e._version, e.data_ptr())
+        if self._half is None or self._half[0] != key:
+            self._half = (key, e.detach().to(torch.half))
+        return self._half[1]
+
+    def forward(self, inputs, bound=1):
+        # inputs: [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
+        inputs = (inputs + bound) / (2 * bound)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        half = None
+        if (torch.is_autocast_enabled("cuda") and self.level_dim % 2 == 0
+                and not (torch.is_grad_enabled() and self.embeddings.requires_grad)):
+            half = self.half_table()
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, half)
+        return outputs.view(prefix_shape + [self.output_dim])
+
+    @torch.amp.autocast("cuda", enabled=False)
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        # gridencoder/grid.py:163-184: adds the TV gradient into embeddings.grad (float32)
+        D = self.input_dim
+        C = self.embeddings.shape[1]
+        L = self.offsets.shape[0] - 1
+        S = float(np.log2(self.per_level_scale))
+        H = self.base_resolution
+        if inputs is None:
+            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            inputs = (inputs + bound) / (2 * bound)
+            inputs = inputs.view(-1, self.input_dim)
+            B = inputs.shape[0]
+        if self.embeddings.grad is None:
+            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
+        inputs = inputs.contiguous().float()
+        hip.call("rn_grad_total_variation", hip.ptr(inputs), hip.ptr(hip.aligned(self.embeddings.detach()), torch.float32),
+                 hip.ptr(self.embeddings.grad, torch.float32), hip.ptr(self.offsets, torch.int32), float(weight), B, D,
+                 C, L, S, H, self.gridtype_id, int(bool(self.align_corners)), hip.stream())

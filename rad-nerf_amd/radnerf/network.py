@@ -1,0 +1,210 @@
+"""Audio-conditioned NeRF network -- host-side mirror of the reference's nerf/network.py.
+
+Same class names, constructor options, attribute / parameter names (so a reference checkpoint's
+state_dict loads unchanged), and the same forward / forward_torso / density / encode_audio /
+get_params contracts.  The encoders come from the drop-in packages of this tree (HIP kernels);
+the per-sample MLP stack can run either as torch Linear layers (the reference's formulation) or,
+for inference, through the fused gfx950 kernel (radnerf.fused).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from activation import trunc_exp
+from encoding import get_encoder
+
+from .renderer import NeRFRenderer
+
+
+class AudioAttNet(nn.Module):
+    """Attention over the 8-frame audio window (nerf/network.py:10-37)."""
+
+    def __init__(self, dim_aud=64, seq_len=8):
+        super().__init__()
+        self.seq_len = seq_len
+        self.dim_aud = dim_aud
+        chans = [dim_aud, 16, 8, 4, 2, 1]
+        layers = []
+        for cin, cout in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv1d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True), nn.LeakyReLU(0.02, True)]
+        self.attentionConvNet = nn.Sequential(*layers)
+        self.attentionNet = nn.Sequential(nn.Linear(seq_len, seq_len, bias=True), nn.Softmax(dim=1))
+
+    def forward(self, x):
+        # x: [1, seq_len, dim_aud] -> [1, dim_aud]
+        y = self.attentionConvNet(x.permute(0, 2, 1))
+        y = self.attentionNet(y.view(1, self.seq_len)).view(1, self.seq_len, 1)
+        return torch.sum(y * x, dim=1)
+
+
+class AudioNet(nn.Module):
+    """Per-frame audio feature extractor (nerf/network.py:41-67)."""
+
+    def __init__(self, dim_in=29, dim_aud=64, win_size=16):
+        super().__init__()
+        self.win_size = win_size
+        self.dim_aud = dim_aud
+        chans = [dim_in, 32, 32, 64, 64]
+        layers = []
+        for cin, cout in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv1d(cin, cout, kernel_size=3, stride=2, padding=1, bias=True), nn.LeakyReLU(0.02, True)]
+        self.encoder_conv = nn.Sequential(*layers)
+        self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), nn.LeakyReLU(0.02, True), nn.Linear(64, dim_aud))
+
+    def forward(self, x):
+        half_w = int(self.win_size / 2)
+        x = x[:, :, 8 - half_w:8 + half_w]
+        x = self.encoder_conv(x).squeeze(-1)
+        return self.encoder_fc1(x)
+
+
+class MLP(nn.Module):
+    """Bias-free Linear stack with ReLU between layers (nerf/network.py:69-88)."""
+
+    def __init__(self, dim_in, dim_out, dim_hidden, num_layers):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hidden, self.num_layers = dim_in, dim_out, dim_hidden, num_layers
+        self.net = nn.ModuleList([
+            nn.Linear(dim_in if l == 0 else dim_hidden, dim_out if l == num_layers - 1 else dim_hidden, bias=False)
+            for l in range(num_layers)])
+
+    def forward(self, x):
+        for l, layer in enumerate(self.net):
+            x = layer(x)
+            if l != self.num_layers - 1:
+                x = F.relu(x, inplace=True)
+        return x
+
+
+class NeRFNetwork(NeRFRenderer):
+    # nerf/network.py:91-167
+    def __init__(self, opt, num_layers=3, hidden_dim=64, geo_feat_dim=64, num_layers_color=2, hidden_dim_color=64,
+                 audio_dim=64, num_layers_ambient=3, hidden_dim_ambient=64, ambient_dim=2):
+        super().__init__(opt)
+
+        self.emb = self.opt.emb
+        if "esperanto" in self.opt.asr_model:
+            self.audio_in_dim = 44
+        elif "deepspeech" in self.opt.asr_model:
+            self.audio_in_dim = 29
+        else:
+            self.audio_in_dim = 32
+        if self.emb:
+            self.embedding = nn.Embedding(self.audio_in_dim, self.audio_in_dim)
+
+        self.audio_dim = audio_dim
+        self.audio_net = AudioNet(self.audio_in_dim, self.audio_dim)
+        self.att = self.opt.att
+        if self.att > 0:
+            self.audio_att_net = AudioAttNet(self.audio_dim)
+
+        grid = dict(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16, interpolation="linear")
+        self.encoder, self.in_dim = get_encoder("tiledgrid", input_dim=3, desired_resolution=2048 * self.bound, **grid)
+        self.encoder_ambient, self.in_dim_ambient = get_encoder("tiledgrid", input_dim=ambient_dim,
+                                                                desired_resolution=2048, **grid)
+        self.num_layers_ambient, self.hidden_dim_ambient, self.ambient_dim = num_layers_ambient, hidden_dim_ambient, ambient_dim
+        self.ambient_net = MLP(self.in_dim + self.audio_dim, self.ambient_dim, self.hidden_dim_ambient, self.num_layers_ambient)
+
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.eye_dim = 1 if self.exp_eye else 0
+        self.sigma_net = MLP(self.in_dim + self.in_dim_ambient + self.eye_dim, 1 + self.geo_feat_dim, self.hidden_dim, self.num_layers)
+
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.encoder_dir, self.in_dim_dir = get_encoder("spherical_harmonics")
+        self.color_net = MLP(self.in_dim_dir + self.geo_feat_dim + self.individual_dim, 3, self.hidden_dim_color, self.num_layers_color)
+
+        if self.torso:
+            self.torso_deform_encoder, self.torso_deform_in_dim = get_encoder("frequency", input_dim=2, multires=10)
+            self.pose_encoder, self.pose_in_dim = get_encoder("frequency", input_dim=6, multires=4)
+            self.torso_deform_net = MLP(self.torso_deform_in_dim + self.pose_in_dim + self.individual_dim_torso, 2, 64, 3)
+            self.torso_encoder, self.torso_in_dim = get_encoder("tiledgrid", input_dim=2, desired_resolution=2048, **grid)
+            self.torso_net = MLP(self.torso_in_dim + self.torso_deform_in_dim + self.pose_in_dim + self.individual_dim_torso, 4, 32, 3)
+
+    def encode_audio(self, a):
+        # nerf/network.py:170-185; a: [8, audio_in_dim, 16] (or [8, 16] ids with --emb) -> [1, audio_dim]
+        if a is None:
+            return None
+        if self.emb:
+            a = self.embedding(a).transpose(-1, -2).contiguous()
+        enc_a = self.audio_net(a)
+        if self.att > 0:
+            enc_a = self.audio_att_net(enc_a.unsqueeze(0))
+        return enc_a
+
+    def forward_torso(self, x, poses, enc_a, c=None):
+        # nerf/network.py:188-219; x: [N,2] in [-1,1], poses: [1,6], c: [ind_dim_torso]
+        x = x * self.opt.torso_shrink
+        enc_pose = self.pose_encoder(poses)
+        enc_x = self.torso_deform_encoder(x)
+        parts = [enc_x, enc_pose.repeat(x.shape[0], 1)]
+        if c is not None:
+            parts.append(c.repeat(x.shape[0], 1))
+        h = torch.cat(parts, dim=-1)
+        dx = self.torso_deform_net(h)
+        x = (x + dx).clamp(-1, 1)
+        x = self.torso_encoder(x, bound=1)
+        h = self.torso_net(torch.cat([x, h], dim=-1))
+        return torch.sigmoid(h[..., :1]), torch.sigmoid(h[..., 1:]), dx
+
+    def _geometry(self, x, enc_a, e):
+        """Shared head of forward() and density(): returns (sigma_net output, ambient)."""
+        if enc_a is None:
+            ambient = torch.zeros_like(x[:, :self.ambient_dim])
+            enc_x = self.encoder(x, bound=self.bound)
+            enc_w = self.encoder_ambient(ambient, bound=1)
+        else:
+            enc_x = self.encoder(x, bound=self.bound)
+            ambient = self.ambient_net(torch.cat([enc_x, enc_a.repeat(x.shape[0], 1)], dim=1)).float()
+            ambient = torch.tanh(ambient)
+            enc_w = self.encoder_ambient(ambient, bound=1)
+        parts = [enc_x, enc_w]
+        if e is not None:
+            parts.append(e.repeat(x.shape[0], 1))
+        return self.sigma_net(torch.cat(parts, dim=-1)), ambient
+
+    def forward(self, x, d, enc_a, c, e=None):
+        # nerf/network.py:222-283; x: [N,3] in [-bound,bound], d: [N,3], enc_a: [1,64], c: [ind_dim], e: [1,1]
+        h, ambient = self._geometry(x, enc_a, e)
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:]
+        enc_d = self.encoder_dir(d)
+        parts = [enc_d, geo_feat]
+        if c is not None:
+            parts.append(c.repeat(x.shape[0], 1))
+        color = torch.sigmoid(self.color_net(torch.cat(parts, dim=-1)))
+        return sigma, color, ambient
+
+    def density(self, x, enc_a, e=None):
+        # nerf/network.py:286-325
+        h, _ = self._geometry(x, enc_a, e)
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def get_params(self, lr, lr_net, wd=0):
+        # nerf/network.py:329-362
+        if self.torso:
+            params = [
+                {"params": self.torso_encoder.parameters(), "lr": lr},
+                {"params": self.torso_net.parameters(), "lr": lr_net, "weight_decay": wd},
+                {"params": self.torso_deform_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            ]
+            if self.individual_dim_torso > 0:
+                params.append({"params": self.individual_codes_torso, "lr": lr_net, "weight_decay": wd})
+            return params
+        params = [
+            {"params": self.audio_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.encoder.parameters(), "lr": lr},
+            {"params": self.encoder_ambient.parameters(), "lr": lr},
+            {"params": self.ambient_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.sigma_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.color_net.parameters(), "lr": lr_net, "weight_decay": wd},
+        ]
+        if self.att > 0:
+            params.append({"params": self.audio_att_net.parameters(), "lr": lr_net * 5, "weight_decay": wd})
+        if self.emb:
+            params.append({"params": self.embedding.parameters(), "lr": lr})
+        if self.individual_dim > 0:
+            params.append({"params": self.individual_codes, "lr": lr_net, "weight_decay": wd})
+        if self.train_camera:
+            params.append({"params": self.camera_dT, "lr": 1e-5, "weight_decay": 0})
+            params.append({"params": self.camera_dR, "lr": 1e-5, "weight_decay": 0})
+        return params
