@@ -73,7 +73,7 @@ def cpu_baseline(scene_kwargs, size, opt_overrides):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     from radnerf.scene import SyntheticScene, default_opt
-    scene = SyntheticScene(H=size, W=size, n_frames=2, device="cpu", opt=default_opt(**opt_overrides), **scene_kwargs)
+    scene = SyntheticScene(H=size, W=size, n_frames=8, device="cpu", opt=default_opt(**opt_overrides), **scene_kwargs)
     m = scene.model
     f = scene.frame(0)
     with torch.no_grad():

@@ -282,10 +282,10 @@ extern "C" {
 
 int rn_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t C, float *dy_dx,
                          rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     RN_REQUIRE(inputs && outputs, "sh_encode_forward: null pointer");
     RN_REQUIRE(D == 3, "SH encoder only support input dim == 3");  // sphere_harmonics.py:69
     RN_REQUIRE(C >= 1 && C <= 8, "SH encoder only supports degree in [1, 8]");
-    if (B == 0) return RN_OK;
     const dim3 grid(div_up(B, kBlockE)), block(kBlockE);
     hipStream_t s = as_stream(stream);
     switch (C) {
@@ -303,10 +303,10 @@ int rn_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32
 
 int rn_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t C,
                           const float *dy_dx, float *grad_inputs, rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     (void)inputs;
     RN_REQUIRE(grad && dy_dx && grad_inputs, "sh_encode_backward: null pointer");
     RN_REQUIRE(D == 3 && C >= 1 && C <= 8, "sh_encode_backward: D must be 3 and degree in [1, 8]");
-    if (B == 0) return RN_OK;
     hipLaunchKernelGGL(k_sh_backward, dim3(div_up(B * D, kBlockE)), dim3(kBlockE), 0, as_stream(stream), grad, B, D,
                        C * C, dy_dx, grad_inputs);
     return check_launch("sh_encode_backward");
@@ -314,9 +314,9 @@ int rn_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, ui
 
 int rn_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs,
                            rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     RN_REQUIRE(inputs && outputs, "freq_encode_forward: null pointer");
     RN_REQUIRE(D >= 1 && C == D + 2 * D * deg, "freq_encode_forward: output_dim must equal D + 2*D*deg");
-    if (B == 0) return RN_OK;
     hipLaunchKernelGGL(k_freq_forward, dim3(div_up(B, kBlockE)), dim3(kBlockE), 0, as_stream(stream), inputs, B, D,
                        deg, C, outputs);
     return check_launch("freq_encode_forward");
@@ -324,9 +324,9 @@ int rn_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t
 
 int rn_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
                             float *grad_inputs, rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     RN_REQUIRE(grad && outputs && grad_inputs, "freq_encode_backward: null pointer");
     RN_REQUIRE(D >= 1 && C == D + 2 * D * deg, "freq_encode_backward: output_dim must equal D + 2*D*deg");
-    if (B == 0) return RN_OK;
     hipLaunchKernelGGL(k_freq_backward, dim3(div_up(B * D, kBlockE)), dim3(kBlockE), 0, as_stream(stream), grad,
                        outputs, B, D, deg, C, grad_inputs);
     return check_launch("freq_encode_backward");

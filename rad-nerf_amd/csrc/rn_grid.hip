@@ -544,12 +544,12 @@ int rn_grid_encode_forward(const float *inputs, const void *embeddings, const in
                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
                            uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int layout,
                            rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     RN_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
     RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L=%u out of range (1..%u)", L, kMaxLevels);
     RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_forward: dtype must be RN_F32 or RN_F16");
     RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_forward: bad layout");
     RN_REQUIRE(gridtype <= 1 && interp <= 1, "grid_encode_forward: bad gridtype / interpolation id");
-    if (B == 0) return RN_OK;
     FwdArgs a{inputs, embeddings, offsets, outputs, B, L, make_level_consts(L, S, H), dy_dx, gridtype,
               align_corners != 0, interp, layout, as_stream(stream)};
     const int rc = (dtype == RN_F32) ? dispatch_fwd_d<float>(D, C, a) : dispatch_fwd_d<__half>(D, C, a);
@@ -561,13 +561,13 @@ int rn_grid_encode_backward(const void *grad, const float *inputs, const void *e
                             void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                             uint32_t H, const void *dy_dx, void *grad_inputs, uint32_t gridtype, int align_corners,
                             uint32_t interp, int dtype, int layout, rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     (void)embeddings;
     RN_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L=%u out of range (1..%u)", L, kMaxLevels);
     RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_backward: dtype must be RN_F32 or RN_F16");
     RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_backward: bad layout");
     RN_REQUIRE(gridtype <= 1 && interp <= 1, "grid_encode_backward: bad gridtype / interpolation id");
-    if (B == 0) return RN_OK;
     BwdArgs a{grad, inputs, offsets, grad_embeddings, B, L, make_level_consts(L, S, H), dy_dx, grad_inputs, gridtype,
               align_corners != 0, interp, layout, as_stream(stream)};
     const int rc = (dtype == RN_F32) ? dispatch_bwd_d<float>(D, C, a) : dispatch_bwd_d<__half>(D, C, a);
@@ -578,9 +578,9 @@ int rn_grid_encode_backward(const void *grad, const float *inputs, const void *e
 int rn_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets,
                             float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                             uint32_t gridtype, int align_corners, rn_stream_t stream) {
+    if (B == 0) return RN_OK;
     RN_REQUIRE(inputs && embeddings && grad && offsets, "grad_total_variation: null pointer");
     RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grad_total_variation: L=%u out of range (1..%u)", L, kMaxLevels);
-    if (B == 0) return RN_OK;
     const LevelConsts lc = make_level_consts(L, S, H);
     int rc;
     switch (D) {

@@ -550,8 +550,8 @@ extern "C" {
 
 int rn_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
                           float min_near, float *nears, float *fars, rn_stream_t stream) {
-    RN_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
     if (N == 0) return RN_OK;
+    RN_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
     hipLaunchKernelGGL(k_near_far, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d,
                        aabb, N, min_near, nears, fars);
     return check_launch("near_far_from_aabb");
@@ -559,32 +559,32 @@ int rn_near_far_from_aabb(const float *rays_o, const float *rays_d, const float 
 
 int rn_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
                     rn_stream_t stream) {
-    RN_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
     if (N == 0) return RN_OK;
+    RN_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
     hipLaunchKernelGGL(k_sph_from_ray, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream), rays_o,
                        rays_d, radius, N, coords);
     return check_launch("sph_from_ray");
 }
 
 int rn_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, rn_stream_t stream) {
-    RN_REQUIRE(coords && indices, "morton3D: null pointer");
     if (N == 0) return RN_OK;
+    RN_REQUIRE(coords && indices, "morton3D: null pointer");
     hipLaunchKernelGGL(k_morton3D, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream), coords, N, indices);
     return check_launch("morton3D");
 }
 
 int rn_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, rn_stream_t stream) {
-    RN_REQUIRE(coords && indices, "morton3D_invert: null pointer");
     if (N == 0) return RN_OK;
+    RN_REQUIRE(coords && indices, "morton3D_invert: null pointer");
     hipLaunchKernelGGL(k_morton3D_invert, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream), indices, N,
                        coords);
     return check_launch("morton3D_invert");
 }
 
 int rn_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
     RN_REQUIRE(grid && bitfield, "packbits: null pointer");
     RN_REQUIRE(((uintptr_t)grid & 15u) == 0, "packbits: grid must be 16-byte aligned");
-    if (N == 0) return RN_OK;
     hipLaunchKernelGGL(k_packbits, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream), grid, N,
                        density_thresh, bitfield);
     return check_launch("packbits");
@@ -607,11 +607,11 @@ int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t 
                         const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                         int32_t *rays, int32_t *counter, const float *noises, void *workspace,
                         rn_stream_t stream) {
+    if (N == 0) return RN_OK;
     RN_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises,
                "march_rays_train: null pointer");
     RN_REQUIRE(workspace, "march_rays_train: workspace of rn_march_rays_train_workspace(N) bytes required");
     RN_REQUIRE(C >= 1 && C <= 16 && H >= 1 && max_steps >= 1, "march_rays_train: bad C/H/max_steps");
-    if (N == 0) return RN_OK;
     uint32_t *block_sums = static_cast<uint32_t *>(workspace);
     const uint32_t blocks = div_up(N, kBlock);
     hipLaunchKernelGGL(k_march_train_count, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, grid,
@@ -627,9 +627,9 @@ int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t 
 int rn_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays,
                                  const float *deltas, uint32_t N, uint32_t M, float *grad_rays_o,
                                  float *grad_rays_d, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
     RN_REQUIRE(grad_xyzs && grad_dirs && rays && deltas && grad_rays_o && grad_rays_d,
                "march_rays_train_backward: null pointer");
-    if (N == 0) return RN_OK;
     hipLaunchKernelGGL(k_march_train_backward, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream),
                        grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d);
     return check_launch("march_rays_train_backward");
@@ -639,9 +639,9 @@ int rn_composite_rays_train_forward(const float *sigmas, const float *rgbs, cons
                                     const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
                                     float T_thresh, float *weights_sum, float *ambient_sum, float *depth,
                                     float *image, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
     RN_REQUIRE(sigmas && rgbs && ambient && deltas && rays && weights_sum && ambient_sum && depth && image,
                "composite_rays_train_forward: null pointer");
-    if (N == 0) return RN_OK;
     hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream), sigmas,
                        rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image);
     return check_launch("composite_rays_train_forward");
@@ -653,11 +653,11 @@ int rn_composite_rays_train_backward(const float *grad_weights_sum, const float 
                                      const float *weights_sum, const float *ambient_sum, const float *image,
                                      uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                      float *grad_rgbs, float *grad_ambient, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
     (void)ambient; (void)ambient_sum;
     RN_REQUIRE(grad_weights_sum && grad_ambient_sum && grad_image && sigmas && rgbs && deltas && rays &&
                    weights_sum && image && grad_sigmas && grad_rgbs && grad_ambient,
                "composite_rays_train_backward: null pointer");
-    if (N == 0) return RN_OK;
     hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up(N, kBlock)), dim3(kBlock), 0, as_stream(stream),
                        grad_weights_sum, grad_ambient_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
                        M, N, T_thresh, grad_sigmas, grad_rgbs, grad_ambient);
@@ -669,11 +669,11 @@ int rn_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, 
                   uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars,
                   float *xyzs, float *dirs, float *deltas, const float *noises, const int32_t *n_alive_dev,
                   rn_stream_t stream) {
+    if (n_alive == 0) return RN_OK;
     (void)nears;
     RN_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas,
                "march_rays: null pointer");
     RN_REQUIRE(C >= 1 && C <= 16 && H >= 1 && max_steps >= 1 && n_step >= 1, "march_rays: bad C/H/max_steps/n_step");
-    if (n_alive == 0) return RN_OK;
     hipLaunchKernelGGL(k_march_rays, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, as_stream(stream), n_alive,
                        n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs,
                        dirs, deltas, noises, n_alive_dev);
@@ -683,10 +683,10 @@ int rn_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, 
 int rn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                       const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum,
                       float *depth, float *image, const int32_t *n_alive_dev, rn_stream_t stream) {
+    if (n_alive == 0) return RN_OK;
     RN_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image,
                "composite_rays: null pointer");
     RN_REQUIRE(n_step >= 1, "composite_rays: n_step must be >= 1");
-    if (n_alive == 0) return RN_OK;
     hipLaunchKernelGGL(k_composite_rays, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, as_stream(stream), n_alive,
                        n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                        n_alive_dev);
@@ -697,9 +697,10 @@ size_t rn_compact_rays_workspace(uint32_t n) { return (size_t)(div_up(n, kCompac
 
 int rn_compact_rays(const int32_t *rays_alive_in, uint32_t n, const int32_t *n_dev, int32_t *rays_alive_out,
                     int32_t *n_out, void *workspace, rn_stream_t stream) {
-    RN_REQUIRE(rays_alive_in && rays_alive_out && n_out && workspace, "compact_rays: null pointer");
-    RN_REQUIRE(rays_alive_in != rays_alive_out, "compact_rays: in-place compaction is not supported");
+    RN_REQUIRE(n_out, "compact_rays: n_out is null");
     if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(int32_t), as_stream(stream)) == hipSuccess ? RN_OK : RN_ERR_LAUNCH;
+    RN_REQUIRE(rays_alive_in && rays_alive_out && workspace, "compact_rays: null pointer");
+    RN_REQUIRE(rays_alive_in != rays_alive_out, "compact_rays: in-place compaction is not supported");
     uint32_t *block_counts = static_cast<uint32_t *>(workspace);
     const uint32_t blocks = div_up(n, kCompactItems);
     hipLaunchKernelGGL(k_compact_count, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_alive_in, n, n_dev,

@@ -182,6 +182,7 @@ class GridEncoder(nn.Module):
         if self.embeddings.grad is None:
             raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
         inputs = inputs.contiguous().float()
-        hip.call("rn_grad_total_variation", hip.ptr(inputs), hip.ptr(hip.aligned(self.embeddings.detach()), torch.float32),
+        table = hip.aligned(self.embeddings.detach())  # named: must outlive the enqueue below
+        hip.call("rn_grad_total_variation", hip.ptr(inputs), hip.ptr(table, torch.float32),
                  hip.ptr(self.embeddings.grad, torch.float32), hip.ptr(self.offsets, torch.int32), float(weight), B, D,
                  C, L, S, H, self.gridtype_id, int(bool(self.align_corners)), hip.stream())

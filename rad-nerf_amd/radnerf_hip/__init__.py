@@ -145,7 +145,11 @@ def dev(t):
 
 
 def ptr(t, dtype=None):
-    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    """Device pointer of a contiguous CUDA tensor (None -> NULL).
+
+    The caller must keep `t` referenced until the C-ABI call has been made: a temporary such as
+    ptr(x.contiguous()) is freed as soon as ptr() returns and its block can be handed out again
+    before the kernel is even enqueued."""
     if t is None:
         return None
     if not t.is_cuda:

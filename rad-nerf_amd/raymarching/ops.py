@@ -148,9 +148,10 @@ class _march_rays_train(Function):
         noises = torch.rand(N, dtype=_f32, device=device) if perturb else torch.zeros(N, dtype=_f32, device=device)
 
         ws = hip.workspace(hip.workspace_bytes("rn_march_rays_train_workspace", N), device)
+        nears, fars = nears.contiguous(), fars.contiguous()  # named: must outlive the enqueue below
         hip.call("rn_march_rays_train", hip.ptr(rays_o, _f32), hip.ptr(rays_d, _f32),
                  hip.ptr(density_bitfield, torch.uint8), float(bound), float(dt_gamma), int(max_steps), N, int(C),
-                 int(H), M, hip.ptr(nears.contiguous(), _f32), hip.ptr(fars.contiguous(), _f32), hip.ptr(xyzs),
+                 int(H), M, hip.ptr(nears, _f32), hip.ptr(fars, _f32), hip.ptr(xyzs),
                  hip.ptr(dirs), hip.ptr(deltas), hip.ptr(rays), hip.ptr(step_counter, torch.int32), hip.ptr(noises),
                  hip.ptr(ws), hip.stream())
 
@@ -172,8 +173,9 @@ class _march_rays_train(Function):
         N, M = rays.shape[0], grad_xyzs.shape[0]
         grad_rays_o = torch.zeros(N, 3, dtype=_f32, device=rays.device)
         grad_rays_d = torch.zeros(N, 3, dtype=_f32, device=rays.device)
-        hip.call("rn_march_rays_train_backward", hip.ptr(grad_xyzs.contiguous(), _f32),
-                 hip.ptr(grad_dirs.contiguous(), _f32), hip.ptr(rays), hip.ptr(deltas.contiguous(), _f32), N, M,
+        grad_xyzs, grad_dirs, deltas = grad_xyzs.contiguous(), grad_dirs.contiguous(), deltas.contiguous()
+        hip.call("rn_march_rays_train_backward", hip.ptr(grad_xyzs, _f32),
+                 hip.ptr(grad_dirs, _f32), hip.ptr(rays), hip.ptr(deltas, _f32), N, M,
                  hip.ptr(grad_rays_o), hip.ptr(grad_rays_d), hip.stream())
         return (grad_rays_o, grad_rays_d) + (None,) * 13
 
@@ -209,8 +211,10 @@ class _composite_rays_train(Function):
         grad_sigmas = torch.zeros_like(sigmas)
         grad_rgbs = torch.zeros_like(rgbs)
         grad_ambient = torch.zeros_like(ambient)
-        hip.call("rn_composite_rays_train_backward", hip.ptr(grad_weights_sum.contiguous(), _f32),
-                 hip.ptr(grad_ambient_sum.contiguous(), _f32), hip.ptr(grad_image.contiguous(), _f32), hip.ptr(sigmas),
+        grad_weights_sum, grad_ambient_sum = grad_weights_sum.contiguous(), grad_ambient_sum.contiguous()
+        grad_image = grad_image.contiguous()
+        hip.call("rn_composite_rays_train_backward", hip.ptr(grad_weights_sum, _f32),
+                 hip.ptr(grad_ambient_sum, _f32), hip.ptr(grad_image, _f32), hip.ptr(sigmas),
                  hip.ptr(rgbs), hip.ptr(ambient), hip.ptr(deltas), hip.ptr(rays), hip.ptr(weights_sum),
                  hip.ptr(ambient_sum), hip.ptr(image), M, N, float(T_thresh), hip.ptr(grad_sigmas), hip.ptr(grad_rgbs),
                  hip.ptr(grad_ambient), hip.stream())
@@ -256,9 +260,10 @@ class _composite_rays(Function):
     @custom_fwd(device_type="cuda", cast_inputs=_f32)
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                 T_thresh=1e-2):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
         hip.call("rn_composite_rays", int(n_alive), int(n_step), float(T_thresh), hip.ptr(rays_alive, torch.int32),
-                 hip.ptr(rays_t, _f32), hip.ptr(sigmas.contiguous(), _f32), hip.ptr(rgbs.contiguous(), _f32),
-                 hip.ptr(deltas.contiguous(), _f32), hip.ptr(weights_sum, _f32), hip.ptr(depth, _f32),
+                 hip.ptr(rays_t, _f32), hip.ptr(sigmas, _f32), hip.ptr(rgbs, _f32),
+                 hip.ptr(deltas, _f32), hip.ptr(weights_sum, _f32), hip.ptr(depth, _f32),
                  hip.ptr(image, _f32), None, hip.stream())
         return tuple()
 

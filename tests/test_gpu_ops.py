@@ -25,6 +25,21 @@ def n(x):
     return x.detach().cpu().numpy()
 
 
+_KEEP = []
+
+
+def dp(a):
+    """Upload a numpy array and return its device pointer; the tensor is kept alive for the test's duration
+    (a temporary would be freed -- and its block reused -- before the kernel is enqueued)."""
+    import radnerf_hip as hip
+    x = t(a)
+    _KEEP.append(x)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return hip.ptr(x)
+
+
 def make_rays(rng, N, spread=0.35):
     """Camera on +y looking at the origin (OrbitCamera convention), plus a few degenerate rays."""
     o = np.tile(np.array([[0.05, 3.3, -0.1]], np.float32), (N, 1))
@@ -133,9 +148,9 @@ def test_march_rays_bit_exact(po, hiplib, rng, N, n_step):
     M = n_alive * n_step + 128 - (n_alive * n_step) % 128
     ex, ed, edl = po.march_rays(n_alive, n_step, alive, rays_t, o, d, 1.0, dt_gamma, max_steps, 1, 128, bits, nears, fars, noises, M=M)
     xyzs = torch.zeros(M, 3, device=DEV); dirs = torch.zeros(M, 3, device=DEV); deltas = torch.zeros(M, 2, device=DEV)
-    hip.call("rn_march_rays", n_alive, n_step, hip.ptr(t(alive)), hip.ptr(t(rays_t)), hip.ptr(t(o)), hip.ptr(t(d)), 1.0,
-             dt_gamma, max_steps, 1, 128, hip.ptr(t(bits)), hip.ptr(t(nears)), hip.ptr(t(fars)), hip.ptr(xyzs),
-             hip.ptr(dirs), hip.ptr(deltas), hip.ptr(t(noises)), None, hip.stream())
+    hip.call("rn_march_rays", n_alive, n_step, dp(alive), dp(rays_t), dp(o), dp(d), 1.0,
+             dt_gamma, max_steps, 1, 128, dp(bits), dp(nears), dp(fars), hip.ptr(xyzs),
+             hip.ptr(dirs), hip.ptr(deltas), dp(noises), None, hip.stream())
     assert np.array_equal(n(xyzs), ex) and np.array_equal(n(dirs), ed) and np.array_equal(n(deltas), edl)
     assert (edl[:, 0] > 0).sum() > 0 or N < 10
 
@@ -207,7 +222,7 @@ def test_compact_rays_stable(hiplib, rng, nn):
 # ------------------------------------------------------------------------------------------------ training path
 
 
-@pytest.mark.parametrize("N,mean_count,force", [(1, -1, False), (4096, -1, False), (4096, 20000, False), (5000, 20000, True)])
+@pytest.mark.parametrize("N,mean_count,force", [(1, -1, False), (4096, -1, False), (4096, 8000, False), (5000, 8000, True)])
 def test_march_rays_train_bit_exact(po, hiplib, rng, N, mean_count, force):
     import raymarching
     o, d = make_rays(rng, N)
@@ -270,7 +285,7 @@ def test_march_rays_train_backward(po, hiplib, rng):
     gx = rng.standard_normal((M, 3)).astype(np.float32); gd = rng.standard_normal((M, 3)).astype(np.float32)
     e_go, e_gd = po.march_rays_train_backward(gx, gd, rays, deltas)
     go = torch.zeros(N, 3, device=DEV); gdd = torch.zeros(N, 3, device=DEV)
-    hip.call("rn_march_rays_train_backward", hip.ptr(t(gx)), hip.ptr(t(gd)), hip.ptr(t(rays)), hip.ptr(t(deltas)), N, M,
+    hip.call("rn_march_rays_train_backward", dp(gx), dp(gd), dp(rays), dp(deltas), N, M,
              hip.ptr(go), hip.ptr(gdd), hip.stream())
     np.testing.assert_array_equal(n(go), e_go)
     np.testing.assert_array_equal(n(gdd), e_gd)
@@ -285,8 +300,9 @@ def _grid_case(rng, D, C, L, log2T, gridtype, B, desired=2048, base=16):
     offsets = level_offsets(D, L, pls, base, log2T, False)
     emb = rng.uniform(-0.5, 0.5, (int(offsets[-1]), C)).astype(np.float32)
     x = rng.uniform(0, 1, (B, D)).astype(np.float32)
-    x[0] = 0.0; x[1] = 1.0
+    x[0] = 0.0
     if B > 4:
+        x[1] = 1.0
         x[2, 0] = -0.01   # out of range -> zeros
         x[3, D - 1] = 1.01
     return offsets, emb, x, float(np.log2(pls))
@@ -314,14 +330,14 @@ def test_grid_forward_fp32_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, 
     e_out, e_dy = po.grid_encode_forward(x, emb, offsets, B, D, C, L, S, 16, True, gridtype, False, interp)
     out = torch.empty((L, B, C) if layout == 0 else (B, L * C), device=DEV)
     dy = torch.empty(B, L * D * C, device=DEV)
-    hip.call("rn_grid_encode_forward", hip.ptr(t(x)), hip.ptr(t(emb)), hip.ptr(t(offsets)), hip.ptr(out), B, D, C, L, S, 16,
+    hip.call("rn_grid_encode_forward", dp(x), dp(emb), dp(offsets), hip.ptr(out), B, D, C, L, S, 16,
              hip.ptr(dy), gridtype, 0, interp, hip.RN_F32, layout, hip.stream())
     got = n(out) if layout == 0 else n(out).reshape(B, L, C).transpose(1, 0, 2)
     assert np.array_equal(got, e_out)
     assert np.array_equal(n(dy), e_dy)
     # without dy_dx the outputs must not change
     out2 = torch.empty_like(out)
-    hip.call("rn_grid_encode_forward", hip.ptr(t(x)), hip.ptr(t(emb)), hip.ptr(t(offsets)), hip.ptr(out2), B, D, C, L, S, 16,
+    hip.call("rn_grid_encode_forward", dp(x), dp(emb), dp(offsets), hip.ptr(out2), B, D, C, L, S, 16,
              None, gridtype, 0, interp, hip.RN_F32, layout, hip.stream())
     assert torch.equal(out, out2)
 
@@ -335,7 +351,7 @@ def test_grid_forward_fp16_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, 
     e_out, e_dy = po.grid_encode_forward(x, emb16, offsets, B, D, C, L, S, 16, True, gridtype, False, 0, half=True)
     out = torch.empty((L, B, C) if layout == 0 else (B, L * C), device=DEV, dtype=torch.half)
     dy = torch.empty(B, L * D * C, device=DEV, dtype=torch.half)
-    hip.call("rn_grid_encode_forward", hip.ptr(t(x)), hip.ptr(t(emb16)), hip.ptr(t(offsets)), hip.ptr(out), B, D, C, L, S, 16,
+    hip.call("rn_grid_encode_forward", dp(x), dp(emb16), dp(offsets), hip.ptr(out), B, D, C, L, S, 16,
              hip.ptr(dy), gridtype, 0, 0, hip.RN_F16, layout, hip.stream())
     got = n(out) if layout == 0 else n(out).reshape(B, L, C).transpose(1, 0, 2)
     assert np.array_equal(got.view(np.uint16), e_out.view(np.uint16))
@@ -353,7 +369,7 @@ def test_grid_forward_align_corners(po, hiplib, rng):
     S = float(np.log2(pls))
     e_out, _ = po.grid_encode_forward(x, emb, offsets, B, D, C, L, S, 16, False, 0, True, 0)
     out = torch.empty(L, B, C, device=DEV)
-    hip.call("rn_grid_encode_forward", hip.ptr(t(x)), hip.ptr(t(emb)), hip.ptr(t(offsets)), hip.ptr(out), B, D, C, L, S, 16,
+    hip.call("rn_grid_encode_forward", dp(x), dp(emb), dp(offsets), hip.ptr(out), B, D, C, L, S, 16,
              None, 0, 1, 0, hip.RN_F32, 0, hip.stream())
     assert np.array_equal(n(out), e_out)
 
@@ -368,8 +384,8 @@ def test_grid_backward_fp32(po, hiplib, rng, D, C, L, log2T, gridtype, B, layout
     e_ge, e_gi = po.grid_encode_backward(grad, x, emb, offsets, B, D, C, L, S, 16, dy, gridtype, False, 0)
     g_in = grad if layout == 0 else np.ascontiguousarray(grad.transpose(1, 0, 2)).reshape(B, L * C)
     ge = torch.zeros(emb.shape, device=DEV); gi = torch.zeros(B, D, device=DEV)
-    hip.call("rn_grid_encode_backward", hip.ptr(t(g_in)), hip.ptr(t(x)), hip.ptr(t(emb)), hip.ptr(t(offsets)), hip.ptr(ge), B, D,
-             C, L, S, 16, hip.ptr(t(dy)), hip.ptr(gi), gridtype, 0, 0, hip.RN_F32, layout, hip.stream())
+    hip.call("rn_grid_encode_backward", dp(g_in), dp(x), dp(emb), dp(offsets), hip.ptr(ge), B, D,
+             C, L, S, 16, dp(dy), hip.ptr(gi), gridtype, 0, 0, hip.RN_F32, layout, hip.stream())
     # scatter-add order differs (atomics): tolerance scaled by the number of colliding adds
     np.testing.assert_allclose(n(ge), e_ge, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(e_ge).max()))
     np.testing.assert_array_equal(n(gi), e_gi)  # sequential per (b, d): same order -> exact
@@ -383,7 +399,7 @@ def test_grid_backward_fp16(po, hiplib, rng):
     grad = (rng.standard_normal((L, B, C)) * 0.1).astype(np.float16)
     e_ge, _ = po.grid_encode_backward(grad, x, emb16, offsets, B, D, C, L, S, 16, None, gridtype, False, 0, half=True)
     ge = torch.zeros(emb.shape, device=DEV, dtype=torch.half)
-    hip.call("rn_grid_encode_backward", hip.ptr(t(grad)), hip.ptr(t(x)), hip.ptr(t(emb16)), hip.ptr(t(offsets)), hip.ptr(ge), B,
+    hip.call("rn_grid_encode_backward", dp(grad), dp(x), dp(emb16), dp(offsets), hip.ptr(ge), B,
              D, C, L, S, 16, None, None, gridtype, 0, 0, hip.RN_F16, 0, hip.stream())
     # half accumulation in arrival order: compare against the fp32 truth with a half-precision tolerance
     t_ge, _ = po.grid_encode_backward(grad.astype(np.float32), x, emb, offsets, B, D, C, L, S, 16, None, gridtype, False, 0)

@@ -25,7 +25,7 @@ def _oracle_frame(po, scene, f, enc_a):
 @pytest.mark.parametrize("engine", ["ops"])
 def test_frame_matches_oracle(po, hiplib, size, engine):
     from radnerf.scene import SyntheticScene, default_opt
-    scene = SyntheticScene(H=size, W=size, n_frames=3, device="cuda", opt=default_opt(engine=engine))
+    scene = SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine=engine))
     for i in range(2):  # second frame exercises the lip-smoothing EMA state
         f = scene.frame(i)
         with torch.no_grad():
@@ -43,7 +43,7 @@ def test_frame_matches_oracle(po, hiplib, size, engine):
 
 def test_network_forward_matches_oracle(po, hiplib):
     from radnerf.scene import SyntheticScene, default_opt
-    scene = SyntheticScene(H=16, W=16, n_frames=1, device="cuda", opt=default_opt())
+    scene = SyntheticScene(H=16, W=16, n_frames=8, device="cuda", opt=default_opt())
     m = scene.model
     rng = np.random.default_rng(3)
     M = 5000

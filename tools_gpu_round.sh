@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests -m gpu -q -x --timeout=600 > gpurun_out/test_gpu.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q --timeout=600 > gpurun_out/test_gpu.log 2>&1
 rc=$?
 tail -n 25 gpurun_out/test_gpu.log
 echo "pytest rc=$rc"
