@@ -4,98 +4,11 @@
 // reference.  Both are streaming kernels (12 B in / 64 B out per sample for the degree-4 SH the
 // model uses): one sample per lane, the whole output row built in registers and written with
 // 16-byte stores.
-#include "rn_common.h"
+#include "rn_sh_dev.h"
 
 namespace rn {
 
 constexpr int kBlockE = 256;
-
-// Real SH basis written as polynomials; the compiler prunes everything past degree C because the
-// degree is a template parameter.  out[] has C*C entries.
-template <uint32_t C>
-__device__ __forceinline__ void sh_basis(float x, float y, float z, float *o) {
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
-    const float x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
-    o[0] = 0.28209479177387814f;
-    if constexpr (C > 1) {
-        o[1] = -0.48860251190291987f * y;
-        o[2] = 0.48860251190291987f * z;
-        o[3] = -0.48860251190291987f * x;
-    }
-    if constexpr (C > 2) {
-        o[4] = 1.0925484305920792f * xy;
-        o[5] = -1.0925484305920792f * yz;
-        o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
-        o[7] = -1.0925484305920792f * xz;
-        o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
-    }
-    if constexpr (C > 3) {
-        o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
-        o[10] = 2.8906114426405538f * xy * z;
-        o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
-        o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
-        o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
-        o[14] = 1.4453057213202769f * z * (x2 - y2);
-        o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
-    }
-    if constexpr (C > 4) {
-        o[16] = 2.5033429417967046f * xy * (x2 - y2);
-        o[17] = 1.7701307697799304f * yz * (-3.0f * x2 + y2);
-        o[18] = 0.94617469575756008f * xy * (7.0f * z2 - 1.0f);
-        o[19] = 0.66904654355728921f * yz * (3.0f - 7.0f * z2);
-        o[20] = -3.1735664074561294f * z2 + 3.7024941420321507f * z4 + 0.31735664074561293f;
-        o[21] = 0.66904654355728921f * xz * (3.0f - 7.0f * z2);
-        o[22] = 0.47308734787878004f * (x2 - y2) * (7.0f * z2 - 1.0f);
-        o[23] = 1.7701307697799304f * xz * (-x2 + 3.0f * y2);
-        o[24] = -3.7550144126950569f * x2 * y2 + 0.62583573544917614f * x4 + 0.62583573544917614f * y4;
-    }
-    if constexpr (C > 5) {
-        o[25] = 0.65638205684017015f * y * (10.0f * x2 * y2 - 5.0f * x4 - y4);
-        o[26] = 8.3026492595241645f * xy * z * (x2 - y2);
-        o[27] = -0.48923829943525038f * y * (3.0f * x2 - y2) * (9.0f * z2 - 1.0f);
-        o[28] = 4.7935367849733241f * xy * z * (3.0f * z2 - 1.0f);
-        o[29] = 0.45294665119569694f * y * (14.0f * z2 - 21.0f * z4 - 1.0f);
-        o[30] = 0.1169503224534236f * z * (-70.0f * z2 + 63.0f * z4 + 15.0f);
-        o[31] = 0.45294665119569694f * x * (14.0f * z2 - 21.0f * z4 - 1.0f);
-        o[32] = 2.3967683924866621f * z * (x2 - y2) * (3.0f * z2 - 1.0f);
-        o[33] = -0.48923829943525038f * x * (x2 - 3.0f * y2) * (9.0f * z2 - 1.0f);
-        o[34] = 2.0756623148810411f * z * (-6.0f * x2 * y2 + x4 + y4);
-        o[35] = 0.65638205684017015f * x * (10.0f * x2 * y2 - x4 - 5.0f * y4);
-    }
-    if constexpr (C > 6) {
-        o[36] = 1.3663682103838286f * xy * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
-        o[37] = 2.3666191622317521f * yz * (10.0f * x2 * y2 - 5.0f * x4 - y4);
-        o[38] = 2.0182596029148963f * xy * (x2 - y2) * (11.0f * z2 - 1.0f);
-        o[39] = -0.92120525951492349f * yz * (3.0f * x2 - y2) * (11.0f * z2 - 3.0f);
-        o[40] = 0.92120525951492349f * xy * (-18.0f * z2 + 33.0f * z4 + 1.0f);
-        o[41] = 0.58262136251873131f * yz * (30.0f * z2 - 33.0f * z4 - 5.0f);
-        o[42] = 6.6747662381009842f * z2 - 20.024298714302954f * z4 + 14.684485723822165f * z6 - 0.31784601133814211f;
-        o[43] = 0.58262136251873131f * xz * (30.0f * z2 - 33.0f * z4 - 5.0f);
-        o[44] = 0.46060262975746175f * (x2 - y2) * (11.0f * z2 * (3.0f * z2 - 1.0f) - 7.0f * z2 + 1.0f);
-        o[45] = -0.92120525951492349f * xz * (x2 - 3.0f * y2) * (11.0f * z2 - 3.0f);
-        o[46] = 0.50456490072872406f * (11.0f * z2 - 1.0f) * (-6.0f * x2 * y2 + x4 + y4);
-        o[47] = 2.3666191622317521f * xz * (10.0f * x2 * y2 - x4 - 5.0f * y4);
-        o[48] = 10.247761577878714f * x2 * y4 - 10.247761577878714f * x4 * y2 + 0.6831841051919143f * x6 - 0.6831841051919143f * y6;
-    }
-    if constexpr (C > 7) {
-        o[49] = 0.70716273252459627f * y * (-21.0f * x2 * y4 + 35.0f * x4 * y2 - 7.0f * x6 + y6);
-        o[50] = 5.2919213236038001f * xy * z * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
-        o[51] = -0.51891557872026028f * y * (13.0f * z2 - 1.0f) * (-10.0f * x2 * y2 + 5.0f * x4 + y4);
-        o[52] = 4.1513246297620823f * xy * z * (x2 - y2) * (13.0f * z2 - 3.0f);
-        o[53] = -0.15645893386229404f * y * (3.0f * x2 - y2) * (13.0f * z2 * (11.0f * z2 - 3.0f) - 27.0f * z2 + 3.0f);
-        o[54] = 0.44253269244498261f * xy * z * (-110.0f * z2 + 143.0f * z4 + 15.0f);
-        o[55] = 0.090331607582517306f * y * (-135.0f * z2 + 495.0f * z4 - 429.0f * z6 + 5.0f);
-        o[56] = 0.068284276912004949f * z * (315.0f * z2 - 693.0f * z4 + 429.0f * z6 - 35.0f);
-        o[57] = 0.090331607582517306f * x * (-135.0f * z2 + 495.0f * z4 - 429.0f * z6 + 5.0f);
-        o[58] = 0.07375544874083044f * z * (x2 - y2) * (143.0f * z2 * (3.0f * z2 - 1.0f) - 187.0f * z2 + 45.0f);
-        o[59] = -0.15645893386229404f * x * (x2 - 3.0f * y2) * (13.0f * z2 * (11.0f * z2 - 3.0f) - 27.0f * z2 + 3.0f);
-        o[60] = 1.0378311574405206f * z * (13.0f * z2 - 3.0f) * (-6.0f * x2 * y2 + x4 + y4);
-        o[61] = -0.51891557872026028f * x * (13.0f * z2 - 1.0f) * (-10.0f * x2 * y2 + x4 + 5.0f * y4);
-        o[62] = 2.6459606618019f * z * (15.0f * x2 * y4 - 15.0f * x4 * y2 + x6 - y6);
-        o[63] = 0.70716273252459627f * x * (-35.0f * x2 * y4 + 21.0f * x4 * y2 - x6 + 7.0f * y6);
-    }
-}
 
 // Jacobian rows d/dx, d/dy, d/dz (shencoder.cu:130-350).  AXIS: 0 = x, 1 = y, 2 = z.
 template <uint32_t C, int AXIS>

@@ -1,0 +1,176 @@
+// rn_grid_dev.h -- device-side building blocks of the grid encoder, shared by the standalone
+// operator (rn_grid.hip) and the fused per-sample network kernel (rn_fused.hip).  Both therefore
+// produce bit-identical features for the same inputs.
+#pragma once
+
+#include "rn_common.h"
+
+namespace rn {
+
+constexpr uint32_t kMaxLevels = 32;
+
+// Per-level constants computed on the HOST with libm (gridencoder.cu:138-139), passed by value.
+struct LevelConsts {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+static inline LevelConsts make_level_consts(uint32_t L, float S, uint32_t H) {
+    LevelConsts lc{};
+    for (uint32_t l = 0; l < L; l++) {
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;
+        lc.scale[l] = scale;
+        lc.resolution[l] = (uint32_t)ceilf(scale) + 1;
+    }
+    return lc;
+}
+
+// ---- scalar helpers ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half_rn(v); }
+
+// One aligned load / store of a C-wide feature row.
+template <typename T, uint32_t C>
+__device__ __forceinline__ void load_row(const T *p, T (&v)[C]) {
+    constexpr uint32_t bytes = sizeof(T) * C;
+    if constexpr (bytes == 2) { *reinterpret_cast<uint16_t *>(v) = *reinterpret_cast<const uint16_t *>(p); }
+    else if constexpr (bytes == 4) { *reinterpret_cast<uint32_t *>(v) = *reinterpret_cast<const uint32_t *>(p); }
+    else if constexpr (bytes == 8) { *reinterpret_cast<uint2 *>(v) = *reinterpret_cast<const uint2 *>(p); }
+    else if constexpr (bytes == 16) { *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(p); }
+    else {
+        static_assert(bytes == 32, "unsupported row width");
+        reinterpret_cast<uint4 *>(v)[0] = reinterpret_cast<const uint4 *>(p)[0];
+        reinterpret_cast<uint4 *>(v)[1] = reinterpret_cast<const uint4 *>(p)[1];
+    }
+}
+template <typename T, uint32_t C>
+__device__ __forceinline__ void store_row(T *p, const T (&v)[C]) {
+    constexpr uint32_t bytes = sizeof(T) * C;
+    if constexpr (bytes == 2) { *reinterpret_cast<uint16_t *>(p) = *reinterpret_cast<const uint16_t *>(v); }
+    else if constexpr (bytes == 4) { *reinterpret_cast<uint32_t *>(p) = *reinterpret_cast<const uint32_t *>(v); }
+    else if constexpr (bytes == 8) { *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(v); }
+    else if constexpr (bytes == 16) { *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(v); }
+    else {
+        static_assert(bytes == 32, "unsupported row width");
+        reinterpret_cast<uint4 *>(p)[0] = reinterpret_cast<const uint4 *>(v)[0];
+        reinterpret_cast<uint4 *>(p)[1] = reinterpret_cast<const uint4 *>(v)[1];
+    }
+}
+
+// gridencoder.cu:50-63
+template <uint32_t D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t (&pos_grid)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t result = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+    return result;
+}
+
+// Row index of a lattice corner (gridencoder.cu:66-84 without the "* C + ch").
+template <uint32_t D>
+__device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
+                                             uint32_t resolution, const uint32_t (&pos_grid)[D]) {
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pos_grid[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
+    return index % hashmap_size;
+}
+
+__device__ __forceinline__ float smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
+__device__ __forceinline__ float smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
+
+// Lattice position of one sample at one level (gridencoder.cu:146-158). Returns false when out of [0,1].
+template <uint32_t D>
+__device__ __forceinline__ void lattice_pos(const float (&in)[D], float scale, bool align_corners, uint32_t interp,
+                                            float (&pos)[D], float (&pos_deriv)[D], uint32_t (&pos_grid)[D]) {
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = in[d] * scale + (align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) {
+            pos_deriv[d] = smoothstep_derivative(pos[d]);
+            pos[d] = smoothstep(pos[d]);
+        } else {
+            pos_deriv[d] = 1.0f;
+        }
+    }
+}
+
+// Interpolated features (and optionally d/dx) of one sample at one level.
+// `grid` already points at the level's first row.  Accumulation follows the reference's
+// scalar_t semantics: results live in T and every += rounds to T (gridencoder.cu:163,186,234).
+template <typename T, uint32_t D, uint32_t C, bool DYDX>
+__device__ __forceinline__ void encode_level(const T *__restrict__ grid, const float (&in)[D], float scale,
+                                             uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
+                                             bool align_corners, uint32_t interp, T (&results)[C],
+                                             T (&grads)[DYDX ? D * C : 1]) {
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+    lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
+
+    // issue all 2^D row loads first, then blend
+    T rows[1 << D][C];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
+        const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        load_row<T, C>(grid + (size_t)row * C, rows[idx]);
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(to_f<T>(results[ch]) + w * to_f<T>(rows[idx][ch]));
+    }
+
+    if constexpr (DYDX) {
+        // gridencoder.cu:200-243; corner `idx` of the (D-1)-face with bit gd cleared / set
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            T rg[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] = from_f<T>(0.0f);
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t corner = 0;  // index into rows[] of the "left" corner
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    const bool hi = (idx >> nd) & 1u;
+                    w *= hi ? pos[d] : 1 - pos[d];
+                    corner |= hi ? (1u << d) : 0u;
+                }
+                const uint32_t left = corner, right = corner | (1u << gd);
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float diff = to_f<T>(from_f<T>(to_f<T>(rows[right][ch]) - to_f<T>(rows[left][ch])));
+                    rg[ch] = from_f<T>(to_f<T>(rg[ch]) + w * diff * pos_deriv[gd]);
+                }
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) grads[gd * C + ch] = rg[ch];
+        }
+    }
+}
+
+}  // namespace rn
