@@ -1,0 +1,134 @@
+/*
+ * radnerf_fused.h -- C ABI of the MI355X-native fused render path of libradnerf_hip.so.
+ *
+ * These entry points have no single counterpart among the reference's pybind functions: they replace
+ * whole stretches of its Python hot loop with a handful of gfx950 kernels, while computing exactly what
+ * that loop computes:
+ *
+ *   rn_nerf_fused_forward   NeRFNetwork.forward (nerf/network.py:222-283): xyz grid -> [enc_x | enc_a] ->
+ *                           ambient MLP -> tanh -> ambient grid -> [enc_x | enc_w | eye] -> sigma MLP ->
+ *                           exp, SH(d) -> [enc_d | geo | ind] -> color MLP -> sigmoid, per sample, as ONE
+ *                           kernel: hash/tiled-grid gathers + fp32 MFMA (v_mfma_f32_32x32x2_f32) tiles with the
+ *                           weights resident in LDS; the broadcast inputs (audio code, eye, individual code)
+ *                           are folded into per-frame bias vectors (rn_nerf_frame_bias).
+ *   rn_head_begin /         the inference branch of NeRFRenderer.run_cuda (nerf/renderer.py:183, 225-262):
+ *   rn_head_iterate         near/far, then the <= max_steps loop {march, network, composite, compact}.  The
+ *                           live-ray count, the n_step policy max(min(N // n_alive, 8), 1) and the loop
+ *                           condition live in device memory, so the host enqueues the loop without reading
+ *                           anything back; compaction is a stable wavefront ballot/prefix-sum scatter.
+ *   rn_torso_fused          the torso pass (nerf/renderer.py:269-299 + nerf/network.py:188-219): bilinear
+ *                           occupancy test, deformation MLP, 2-D grid, torso MLP, blend over the background.
+ *   rn_blend_frame          image + (1 - weights_sum) * bg, clamp, depth normalisation (renderer.py:306-311).
+ *
+ * Conventions are those of radnerf_hip.h (device pointers, caller allocates, explicit stream, int status).
+ * Supported network shape (validated; anything else returns RN_ERR_INVALID_ARG and the caller must use the
+ * per-operator path): grids L=16, C=2 (xyz D=3, ambient/torso D=2), hidden width 64, geo_feat 64, SH degree
+ * 4, ambient_dim 2; audio_dim, eye and individual-code widths are free (they only enter the bias vectors).
+ */
+#ifndef RADNERF_FUSED_H
+#define RADNERF_FUSED_H
+
+#include "radnerf_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One multiresolution grid as GridEncoder holds it (gridencoder/grid.py:96-161). */
+typedef struct {
+    const void *embeddings;  /* [rows, 2], float32 or float16 */
+    const int32_t *offsets;  /* [L+1] */
+    uint32_t D, L, H;        /* input dim, levels (16), base resolution */
+    float S;                 /* log2(per_level_scale) */
+    uint32_t gridtype;       /* 0 hash, 1 tiled */
+    int dtype;               /* RN_F32 / RN_F16 */
+} rn_grid_t;
+
+/* Raw nn.Linear weights ([out, in] row-major, bias-free) of the per-sample MLPs (nerf/network.py:140-167). */
+typedef struct {
+    const float *amb_w0, *amb_w1, *amb_w2; /* ambient_net: [64, 32+audio_dim] [64,64] [2,64]      */
+    const float *sig_w0, *sig_w1, *sig_w2; /* sigma_net:   [64, 64+has_eye]   [64,64] [65,64]     */
+    const float *col_w0, *col_w1;          /* color_net:   [64, 80+ind_dim]   [3,64]              */
+    uint32_t audio_dim, has_eye, ind_dim;
+} rn_nerf_weights_t;
+
+/* Number of floats of the packed (MFMA-ordered) weight image / of the per-frame bias block. */
+size_t rn_nerf_packed_floats(void);
+size_t rn_nerf_bias_floats(void);
+/* Re-order the raw weights into the image the fused kernel stages into LDS (call when weights change). */
+int rn_nerf_pack_weights(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);
+/* Per-frame bias vectors: W0_amb[:,32:] enc_a | W0_sig[:,64] eye | W0_col[:,80:] ind_code  (3 x 64). */
+int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
+                       float *bias, rn_stream_t stream);
+
+/* NeRFNetwork.forward for M sample slots.  deltas (nullable): when given, slots with deltas[2*i] == 0 are
+ * dead (raymarching.cu:982) and skipped -- their outputs are left untouched.  m_dev (nullable): device
+ * count of slots, overrides M (M is then only the launch bound).  ambient (nullable): [M,2] output. */
+int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *deltas, uint32_t M,
+                          const int32_t *m_dev, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb,
+                          const float *packed, const float *bias, float bound, float *sigmas, float *rgbs,
+                          float *ambient, rn_stream_t stream);
+
+/* ---- device-side inference loop ------------------------------------------------------------------ */
+#define RN_HEAD_STATE_INTS 32 /* int32 words of loop state the caller provides (zeroing not required) */
+
+typedef struct {
+    /* inputs */
+    const float *rays_o, *rays_d; /* [N,3] */
+    uint32_t N;
+    const float *aabb;            /* [6] */
+    float min_near;
+    const uint8_t *bitfield;
+    float bound, dt_gamma;
+    uint32_t max_steps, cascade, grid_size;
+    float T_thresh;
+    /* outputs */
+    float *nears, *fars;                  /* [N] */
+    float *weights_sum, *depth, *image;   /* [N] [N] [N,3] (zeroed by rn_head_begin) */
+    /* scratch, caller-allocated: N slots are always enough (n_alive * n_step <= N) */
+    int32_t *rays_alive_a, *rays_alive_b; /* [N] each */
+    float *rays_t;                        /* [N] */
+    float *xyzs, *dirs, *deltas;          /* [N,3] [N,3] [N,2] */
+    float *sigmas, *rgbs;                 /* [N] [N,3] */
+    int32_t *state;                       /* [RN_HEAD_STATE_INTS] */
+    uint32_t *block_counts;               /* [ceil(N/256) + 1] */
+} rn_head_t;
+
+/* near/far + loop initialisation (rays_alive = arange(N), rays_t = nears, accumulators = 0, step = 0). */
+int rn_head_begin(const rn_head_t *h, rn_stream_t stream);
+/* Enqueue loop iterations first_iter .. first_iter + n_iters - 1.  Iterations past the end of the loop
+ * (step >= max_steps or no ray alive) are no-ops decided on the device. */
+int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
+                    const float *bias, uint32_t first_iter, uint32_t n_iters, rn_stream_t stream);
+/* Layout of h->state after the loop (int32 words): */
+#define RN_HEAD_ST_ACTIVE 4      /* state[(iter & 1) * 8 + 4]: 1 while the loop wants another iteration */
+#define RN_HEAD_ST_ITERS 16      /* iterations that did work */
+#define RN_HEAD_ST_LIVE 17       /* live samples evaluated (low 32 bits), */
+#define RN_HEAD_ST_SLOTS 18      /* sample slots n_alive * n_step summed over iterations */
+
+/* ---- torso + blend ----------------------------------------------------------------------------------- */
+typedef struct {
+    const float *def_w0, *def_w1, *def_w2; /* torso_deform_net: [64, 96+ind] [64,64] [2,64]  */
+    const float *tor_w0, *tor_w1, *tor_w2; /* torso_net:        [32, 128+ind] [32,32] [4,32] */
+    uint32_t ind_dim;
+} rn_torso_weights_t;
+
+size_t rn_torso_packed_floats(void);
+int rn_torso_pack_weights(const rn_torso_weights_t *w, float *packed, rn_stream_t stream);
+/* bg_out[i] = torso_color * alpha + bg_in[i] * (1 - alpha) for pixels whose bilinear torso occupancy exceeds
+ * `thresh`, else bg_in[i].  bg_in may be NULL (= white, the reference's `bg_color = 1`).
+ * torso_alpha (nullable) [N], deform (nullable) [N,2] receive the per-pixel values (0 where masked out). */
+int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size,
+                   float thresh, const float *poses6, const float *ind_code, float torso_shrink,
+                   const rn_torso_weights_t *w, const float *packed, const rn_grid_t *grid_torso,
+                   const float *bg_in, float *bg_out, float *torso_alpha, float *deform, rn_stream_t stream);
+
+/* image = clamp(image + (1 - weights_sum) * bg, 0, 1); depth = max(depth - near, 0) / (far - near);
+ * optional uint8 quantisation of the frame (image_u8 nullable): floor(image * 255). */
+int rn_blend_frame(float *image, const float *weights_sum, const float *bg, float *depth, const float *nears,
+                   const float *fars, uint32_t N, uint8_t *image_u8, rn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADNERF_FUSED_H */

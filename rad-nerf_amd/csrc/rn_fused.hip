@@ -1,0 +1,998 @@
+// rn_fused.hip -- the fused per-sample network kernel and the device-side inference loop (gfx950).
+//
+// C ABI: include/radnerf_fused.h.  What is computed: nerf/network.py:222-283 per sample and the inference
+// branch of nerf/renderer.py:225-262 per frame.  How (MI355X-first):
+//
+//  * one wavefront owns a tile of 64 samples.  Gather phases run one sample per lane (multires grid rows
+//    fetched with 8-byte loads, same device code as the standalone encoder, so features are bit-identical);
+//    MLP phases run on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains): outputs on the
+//    32 rows of the tile, samples on its 32 columns, two column tiles (= 64 samples) per wave so every
+//    weight fragment read from LDS feeds two MFMAs.
+//  * lane l of an MFMA supplies B[k = l>>5][col = l&31]; one v_permlane32_swap per feature pair turns the
+//    "one sample per lane" registers into the B operands of both column tiles.  A 32x32 accumulator has the
+//    sample on the lane and the output row on the register index, i.e. it already IS the B operand of the
+//    next layer (k order permuted -- the weight image is packed in that order once, on the device).
+//  * all weights (95.7 KB fp32) sit in LDS for the lifetime of a persistent 512-thread workgroup (one per
+//    CU, two waves per SIMD so one wave's gathers overlap the other's MFMAs).
+//  * inputs that are the same for every sample of a frame (audio code, eye, individual code) never enter
+//    the per-sample GEMMs: they are folded into 3 x 64 bias values per frame, used as the accumulators'
+//    initial value.  Outputs narrower than a tile (ambient 2, sigma 1, rgb 3) are VALU dot products over
+//    the accumulator registers + one cross-half shuffle.
+//  * the inference loop keeps n_alive / step / n_step in device memory (double-buffered state words), so
+//    a frame is enqueued without a single host read-back; compaction is a stable ballot/mbcnt scatter.
+#include "rn_dda_dev.h"
+#include "rn_grid_dev.h"
+#include "rn_sh_dev.h"
+
+#include "../../include/radnerf_fused.h"
+
+#include <float.h>
+
+namespace rn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFusedThreads = 512;
+constexpr int kWavesPerBlock = kFusedThreads / kWave;
+
+// ---- packed weight image (floats) --------------------------------------------------------------------
+// MFMA layers: [step][h][col j][row tile] -> lane (j, h) reads one float2 per step.
+constexpr int kStep = 128;                           // floats per MFMA step (2 halves x 32 lanes x 2 row tiles)
+constexpr int OFF_A0 = 0;                            // ambient L0, enc_x part : 16 steps
+constexpr int OFF_A1 = OFF_A0 + 16 * kStep;          // ambient L1            : 32 steps
+constexpr int OFF_A2 = OFF_A1 + 32 * kStep;          // ambient L2 (VALU)     : [2 out][2 h][32]
+constexpr int OFF_S0 = OFF_A2 + 128;                 // sigma L0 (enc_x|enc_w): 32 steps
+constexpr int OFF_S1 = OFF_S0 + 32 * kStep;          // sigma L1              : 32 steps
+constexpr int OFF_S2 = OFF_S1 + 32 * kStep;          // sigma L2 rows 1..64   : 32 steps
+constexpr int OFF_S2R = OFF_S2 + 32 * kStep;         // sigma L2 row 0 (VALU) : [2 h][32]
+constexpr int OFF_C0 = OFF_S2R + 64;                 // color L0 (sh | geo)   : 8 + 32 steps
+constexpr int OFF_C1 = OFF_C0 + 40 * kStep;          // color L1 (VALU)       : [3 out][2 h][32]
+constexpr int kPacked = OFF_C1 + 192;                // 23936 floats
+constexpr int kBias = 192;                           // amb | sig | col, 64 each
+constexpr int kLdsFloats = kPacked + kBias;          // 96512 B of LDS
+
+__host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// k index (within a 64-wide hidden vector) that lane-half h feeds at MFMA step s when the B operand is
+// register (s & 15) of row tile (s >> 4) of the previous layer's accumulators.
+__host__ __device__ constexpr int kmap(int s, int h) { return 32 * (s >> 4) + rowmap(s & 15, h); }
+
+struct RawW {
+    const float *amb_w0, *amb_w1, *amb_w2, *sig_w0, *sig_w1, *sig_w2, *col_w0, *col_w1;
+    uint32_t audio_dim, has_eye, ind_dim;
+};
+
+__global__ void __launch_bounds__(256) k_pack_nerf(RawW w, float *__restrict__ packed) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kPacked) return;
+    const int ldA0 = 32 + (int)w.audio_dim, ldS0 = 64 + (int)w.has_eye, ldC0 = 80 + (int)w.ind_dim;
+    float v;
+    auto mfma_elem = [&](int base, const float *src, int ld, int kind) -> float {
+        const int q = e - base, s = q / kStep, rem = q % kStep;
+        const int h = rem / 64, j = (rem % 64) / 2, rt = rem % 2;
+        const int row = 32 * rt + j;
+        int k;
+        if (kind == 0) k = 2 * s + h;                                  // natural feature pairs
+        else if (kind == 1) k = kmap(s, h);                            // previous accumulators
+        else k = (s < 8) ? 2 * s + h : 16 + kmap(s - 8, h);            // color L0: sh pairs then geo accumulators
+        return src[row * ld + k];
+    };
+    auto valu_elem = [&](int base, const float *src) -> float {        // [out][h][q], q = rt*16 + r
+        const int q0 = e - base, o = q0 / 64, h = (q0 % 64) / 32, q = q0 % 32;
+        return src[o * 64 + 32 * (q >> 4) + rowmap(q & 15, h)];
+    };
+    if (e < OFF_A1) v = mfma_elem(OFF_A0, w.amb_w0, ldA0, 0);
+    else if (e < OFF_A2) v = mfma_elem(OFF_A1, w.amb_w1, 64, 1);
+    else if (e < OFF_S0) v = valu_elem(OFF_A2, w.amb_w2);
+    else if (e < OFF_S1) v = mfma_elem(OFF_S0, w.sig_w0, ldS0, 0);
+    else if (e < OFF_S2) v = mfma_elem(OFF_S1, w.sig_w1, 64, 1);
+    else if (e < OFF_S2R) v = mfma_elem(OFF_S2, w.sig_w2 + 64, 64, 1);  // rows 1..64 = geo_feat
+    else if (e < OFF_C0) v = valu_elem(OFF_S2R, w.sig_w2);              // row 0 = sigma
+    else if (e < OFF_C1) v = mfma_elem(OFF_C0, w.col_w0, ldC0, 2);
+    else v = valu_elem(OFF_C1, w.col_w1);
+    packed[e] = v;
+}
+
+// Per-frame bias vectors (the broadcast columns of the three first layers).
+__global__ void __launch_bounds__(kBias) k_frame_bias(RawW w, const float *__restrict__ enc_a,
+                                                      const float *__restrict__ eye,
+                                                      const float *__restrict__ ind_code, float *__restrict__ bias) {
+    const int t = threadIdx.x, row = t & 63;
+    float acc = 0.0f;
+    if (t < 64) {
+        const float *r = w.amb_w0 + row * (32 + w.audio_dim) + 32;
+        for (uint32_t a = 0; a < w.audio_dim; a++) acc += r[a] * enc_a[a];
+    } else if (t < 128) {
+        if (w.has_eye) acc = w.sig_w0[row * 65 + 64] * eye[0];
+    } else {
+        const float *r = w.col_w0 + row * (80 + w.ind_dim) + 80;
+        for (uint32_t c = 0; c < w.ind_dim; c++) acc += r[c] * ind_code[c];
+    }
+    bias[t] = acc;
+}
+
+// ---- MFMA helpers ---------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// acc[column tile][row tile]
+struct Acc {
+    f32x16 v[2][2];
+};
+
+__device__ __forceinline__ void acc_zero(Acc &a) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = 0.0f;
+}
+
+// accumulator rows of lane half h: 32 rt + (r & 3) + 8 (r >> 2) + 4 h -> four consecutive floats per r >> 2
+__device__ __forceinline__ void acc_bias(Acc &a, const float *bias64, int h) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias64 + 32 * rt + 8 * g + 4 * h);
+            a.v[0][rt][4 * g + 0] = b.x; a.v[0][rt][4 * g + 1] = b.y; a.v[0][rt][4 * g + 2] = b.z; a.v[0][rt][4 * g + 3] = b.w;
+            a.v[1][rt][4 * g + 0] = b.x; a.v[1][rt][4 * g + 1] = b.y; a.v[1][rt][4 * g + 2] = b.z; a.v[1][rt][4 * g + 3] = b.w;
+        }
+}
+
+__device__ __forceinline__ void acc_relu(Acc &a) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = fmaxf(a.v[nt][rt][r], 0.0f);
+}
+
+// one MFMA step of a 64-row layer: weights of step s from LDS, B operands b0 / b1 for the two column tiles
+__device__ __forceinline__ void step64(Acc &a, const float *wl, int s, int lane_off, float b0, float b1) {
+    const float2 w = *reinterpret_cast<const float2 *>(wl + s * kStep + lane_off);
+    a.v[0][0] = mfma32(w.x, b0, a.v[0][0]);
+    a.v[1][0] = mfma32(w.x, b1, a.v[1][0]);
+    a.v[0][1] = mfma32(w.y, b0, a.v[0][1]);
+    a.v[1][1] = mfma32(w.y, b1, a.v[1][1]);
+}
+
+// 64 -> 64 layer whose input is the previous layer's accumulators (32 steps)
+__device__ __forceinline__ void layer_from_acc(Acc &out, const Acc &in, const float *wl, int lane_off) {
+#pragma unroll
+    for (int s = 0; s < 32; s++) step64(out, wl, s, lane_off, in.v[0][s >> 4][s & 15], in.v[1][s >> 4][s & 15]);
+}
+
+// out[o] (both column tiles) = sum_k in[k] * W[o][k] with the k's this lane holds; caller adds the other half
+template <int NOUT>
+__device__ __forceinline__ void valu_out(const Acc &in, const float *wl, int h, float (&part)[2][NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) {
+        float p0 = 0.0f, p1 = 0.0f;
+        const float *wo = wl + (o * 2 + h) * 32;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const float4 w = *reinterpret_cast<const float4 *>(wo + 4 * g);
+            const int rt = g >> 2, r = (g & 3) * 4;
+            p0 = __builtin_fmaf(in.v[0][rt][r + 0], w.x, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 0], w.x, p1);
+            p0 = __builtin_fmaf(in.v[0][rt][r + 1], w.y, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 1], w.y, p1);
+            p0 = __builtin_fmaf(in.v[0][rt][r + 2], w.z, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 2], w.z, p1);
+            p0 = __builtin_fmaf(in.v[0][rt][r + 3], w.w, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 3], w.w, p1);
+        }
+        part[0][o] = p0 + __shfl_xor(p0, 32, 64);
+        part[1][o] = p1 + __shfl_xor(p1, 32, 64);
+    }
+}
+
+// "one sample per lane" feature pair (f0, f1) -> B operands of column tile 0 and 1
+__device__ __forceinline__ void to_b_operands(float f0, float f1, float &b0, float &b1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(f0), __float_as_uint(f1), false, false);
+    b0 = __uint_as_float(r[0]);
+    b1 = __uint_as_float(r[1]);
+}
+
+struct GridArgs {
+    const void *table;
+    const int32_t *offsets;
+    LevelConsts lc;
+    uint32_t gridtype;
+};
+
+struct FusedParams {
+    const float *xyzs, *dirs, *deltas;
+    uint32_t M;
+    const int32_t *m_dev;
+    GridArgs gx, gw;
+    const float *packed, *bias;
+    float bound;
+    float *sigmas, *rgbs, *ambient;
+};
+
+// Per-level constants staged in LDS so that the level loops can stay rolled (a by-value kernel argument
+// indexed at run time would be copied to scratch).
+struct LevelLds {
+    float scale;
+    uint32_t resolution, offset, rows;
+};
+
+// Features (2 channels) of one sample at one level; zeros when `on` is false.
+template <typename TT, uint32_t D>
+__device__ __forceinline__ void level_features(const void *table, const LevelLds &lv, uint32_t gridtype,
+                                               const float (&in)[D], bool on, float &f0, float &f1) {
+    f0 = 0.0f;
+    f1 = 0.0f;
+    if (on) {
+        TT res[2];
+        TT dummy[1];
+        encode_level<TT, D, 2, false>(static_cast<const TT *>(table) + (size_t)lv.offset * 2, in, lv.scale, lv.resolution,
+                                      lv.rows, gridtype, false, 0, res, dummy);
+        f0 = to_f<TT>(res[0]);
+        f1 = to_f<TT>(res[1]);
+    }
+}
+
+template <typename TX, typename TW>
+__global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    __shared__ LevelLds lvl_x[16], lvl_w[16];
+
+    uint32_t M = p.M;
+    if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
+    const uint32_t n_tiles = (M + 63u) >> 6;
+    if (blockIdx.x * kWavesPerBlock >= n_tiles) return;  // nothing for this workgroup (uniform)
+
+    for (int i = threadIdx.x; i < kPacked / 4; i += kFusedThreads)
+        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
+    if (threadIdx.x < kBias) lds[kPacked + threadIdx.x] = p.bias[threadIdx.x];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        const uint32_t ox = (uint32_t)p.gx.offsets[t], ow = (uint32_t)p.gw.offsets[t];
+        lvl_x[t] = LevelLds{p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox};
+        lvl_w[t] = LevelLds{p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow};
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int lane_off = h * 64 + j * 2;
+    const float *bias_amb = lds + kPacked, *bias_sig = lds + kPacked + 64, *bias_col = lds + kPacked + 128;
+
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+        const uint32_t sample = tile * 64 + lane;
+        bool live = sample < M;
+        if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;
+        if (__ballot(live) == 0ull) continue;  // whole tile dead (wave-uniform)
+
+        // ---- xyz grid, one sample per lane (gridencoder/grid.py:145-161: (x + bound) / (2 bound)).  Each level's
+        // feature pair goes straight into MFMA step `l` of BOTH first layers that consume enc_x (ambient L0 and
+        // sigma L0), so enc_x is never kept in registers.
+        Acc a0, a1, a2;
+        acc_bias(a0, bias_amb, h);  // ambient L0 accumulators, start = W0[:, 32:] enc_a
+        acc_bias(a2, bias_sig, h);  // sigma   L0 accumulators, start = W0[:, 64] eye
+        {
+            float in[3] = {0.0f, 0.0f, 0.0f};
+            bool on = live;
+            if (live) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    in[d] = (p.xyzs[3 * (size_t)sample + d] + p.bound) / (2 * p.bound);
+                    on = on && !(in[d] < 0 || in[d] > 1);
+                }
+            }
+#pragma unroll 2
+            for (int l = 0; l < 16; l++) {
+                float f0, f1, b0, b1;
+                level_features<TX, 3>(p.gx.table, lvl_x[l], p.gx.gridtype, in, on, f0, f1);
+                to_b_operands(f0, f1, b0, b1);
+                step64(a0, lds + OFF_A0, l, lane_off, b0, b1);
+                step64(a2, lds + OFF_S0, l, lane_off, b0, b1);
+            }
+        }
+
+        // ---- ambient net: [enc_x | enc_a] 96 -> 64 -> 64 -> 2, tanh
+        acc_relu(a0);
+        acc_zero(a1);
+        layer_from_acc(a1, a0, lds + OFF_A1, lane_off);
+        acc_relu(a1);
+        float amb[2];
+        {
+            float part[2][2];
+            valu_out<2>(a1, lds + OFF_A2, h, part);
+            amb[0] = tanhf(h ? part[1][0] : part[0][0]);
+            amb[1] = tanhf(h ? part[1][1] : part[0][1]);
+        }
+        if (p.ambient && live) {
+            p.ambient[2 * (size_t)sample] = amb[0];
+            p.ambient[2 * (size_t)sample + 1] = amb[1];
+        }
+
+        // ---- ambient grid: enc_w = encoder_ambient(ambient, bound=1) -> sigma L0 steps 16..31
+        {
+            float in[2] = {(amb[0] + 1.0f) / 2.0f, (amb[1] + 1.0f) / 2.0f};
+            const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
+#pragma unroll 2
+            for (int l = 0; l < 16; l++) {
+                float f0, f1, b0, b1;
+                level_features<TW, 2>(p.gw.table, lvl_w[l], p.gw.gridtype, in, on, f0, f1);
+                to_b_operands(f0, f1, b0, b1);
+                step64(a2, lds + OFF_S0, 16 + l, lane_off, b0, b1);
+            }
+        }
+
+        // ---- sigma net: [enc_x | enc_w | eye] 65 -> 64 -> 64 -> 1 + 64
+        acc_relu(a2);
+        acc_zero(a1);
+        layer_from_acc(a1, a2, lds + OFF_S1, lane_off);
+        acc_relu(a1);
+        float sigma;
+        {
+            float part[2][1];
+            valu_out<1>(a1, lds + OFF_S2R, h, part);
+            sigma = expf(h ? part[1][0] : part[0][0]);  // trunc_exp forward (activation.py:9-11)
+        }
+        acc_zero(a0);
+        layer_from_acc(a0, a1, lds + OFF_S2, lane_off);  // geo_feat (no activation)
+
+        // ---- color net: [SH(d) | geo_feat | ind_code] 84 -> 64 -> 3, sigmoid
+        acc_bias(a1, bias_col, h);
+        {
+            float sh[16];
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            if (live) {
+                dx = p.dirs[3 * (size_t)sample]; dy = p.dirs[3 * (size_t)sample + 1]; dz = p.dirs[3 * (size_t)sample + 2];
+            }
+            sh_basis<4>(dx, dy, dz, sh);
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                float b0, b1;
+                to_b_operands(sh[2 * s], sh[2 * s + 1], b0, b1);
+                step64(a1, lds + OFF_C0, s, lane_off, b0, b1);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; s++) step64(a1, lds + OFF_C0, 8 + s, lane_off, a0.v[0][s >> 4][s & 15], a0.v[1][s >> 4][s & 15]);
+        acc_relu(a1);
+        {
+            float part[2][3];
+            valu_out<3>(a1, lds + OFF_C1, h, part);
+            if (live) {
+                p.sigmas[sample] = sigma;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float x = h ? part[1][c] : part[0][c];
+                    p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-x));
+                }
+            }
+        }
+    }
+}
+
+// ==========================================================================================================
+// Device-side inference loop (nerf/renderer.py:225-262)
+//
+// state words (int32), two banks of 8 selected by (iteration & 1):
+//   [0] n_alive  [1] step  [2] n_step  [3] M = n_alive * n_step  [4] active
+// plus stats at [16..]: iterations that did work, live samples, sample slots.
+constexpr int kLoopBlock = 256;
+
+__device__ __forceinline__ void next_state(int32_t *st, uint32_t N, uint32_t n_alive, uint32_t step, uint32_t max_steps) {
+    uint32_t n_step = n_alive ? N / n_alive : 1u;   // max(min(N // n_alive, 8), 1)  (renderer.py:249)
+    n_step = n_step > 8u ? 8u : n_step;
+    n_step = n_step < 1u ? 1u : n_step;
+    const bool active = step < max_steps && n_alive > 0;
+    st[0] = (int32_t)n_alive;
+    st[1] = (int32_t)step;
+    st[2] = (int32_t)n_step;
+    st[3] = active ? (int32_t)(n_alive * n_step) : 0;  // sample slots of the coming iteration (0: loop is over)
+    st[4] = active ? 1 : 0;
+}
+
+// near/far (raymarching.cu:91-145) + loop initialisation (renderer.py:229-237)
+__global__ void __launch_bounds__(kLoopBlock)
+k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
+             uint32_t N, float min_near, uint32_t max_steps, float *__restrict__ nears, float *__restrict__ fars,
+             float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+             int32_t *__restrict__ rays_alive, float *__restrict__ rays_t, int32_t *__restrict__ state) {
+    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
+    if (n == 0) {
+        next_state(state, N, N, 0, max_steps);
+        for (int i = 8; i < RN_HEAD_STATE_INTS; i++) state[i] = 0;
+    }
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { float c = near; near = far; far = c; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+    bool miss = (near > far_y || near_y > far);
+    if (!miss) {
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+        if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+        miss = (near > far_z || near_z > far);
+        if (!miss) {
+            if (near_z > near) near = near_z;
+            if (far_z < far) far = far_z;
+            if (near < min_near) near = min_near;
+        }
+    }
+    near = miss ? FLT_MAX : near;
+    far = miss ? FLT_MAX : far;
+    nears[n] = near; fars[n] = far;
+    rays_t[n] = near;
+    rays_alive[n] = (int32_t)n;
+    weights_sum[n] = 0.0f; depth[n] = 0.0f;
+    image[n * 3] = 0.0f; image[n * 3 + 1] = 0.0f; image[n * 3 + 2] = 0.0f;
+}
+
+// raymarching.cu:827-929 with device-resident n_alive / n_step; every slot of a live ray is written
+// (unused slots get deltas = 0), so the sample buffers never need a memset.
+__global__ void __launch_bounds__(kLoopBlock)
+k_head_march(const int32_t *__restrict__ st, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
+             const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, float dt_gamma,
+             uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
+             const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+             float *__restrict__ deltas, int32_t *__restrict__ stats) {
+    if (!st[4]) return;
+    const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
+    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
+    uint32_t emitted = 0;
+    if (n < n_alive) {
+        const int index = rays_alive[n];
+        Dda s;
+        s.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
+        float t = rays_t[index];  // perturb is off at inference: no noise term (renderer.py:251)
+        const size_t base = (size_t)n * n_step;
+        emitted = s.walk<true>(t, n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+        for (uint32_t k = emitted; k < n_step; k++) { deltas[(base + k) * 2] = 0.0f; deltas[(base + k) * 2 + 1] = 0.0f; }
+    }
+    // stats: live samples of this iteration (one atomic per wavefront)
+    for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off, 64);
+    if ((threadIdx.x & 63) == 0 && emitted) atomicAdd(&stats[RN_HEAD_ST_LIVE], (int32_t)emitted);
+    if (n == 0) { atomicAdd(&stats[RN_HEAD_ST_ITERS], 1); atomicAdd(&stats[RN_HEAD_ST_SLOTS], (int32_t)(n_alive * n_step)); }
+}
+
+// raymarching.cu:942-1029 + per-block survivor counts for the compaction that follows
+__global__ void __launch_bounds__(kLoopBlock)
+k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__restrict__ rays_alive,
+                 float *__restrict__ rays_t, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                 const float *__restrict__ deltas, float *__restrict__ weights_sum, float *__restrict__ depth,
+                 float *__restrict__ image, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t wave_cnt[kLoopBlock / kWave];
+    if (!st[4]) return;
+    const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
+    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
+    if (blockIdx.x * kLoopBlock >= n_alive) return;
+    bool survive = false;
+    if (n < n_alive) {
+        const int index = rays_alive[n];
+        const float *sg = sigmas + (size_t)n * n_step;
+        const float *rg = rgbs + (size_t)n * n_step * 3;
+        const float *dl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        float weight_sum = weights_sum[index];
+        float d = depth[index];
+        float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+        uint32_t step = 0;
+        while (step < n_step) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - __expf(-sg[0] * dl[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t = dl[1];
+            d += weight * t;
+            r += weight * rg[0]; g += weight * rg[1]; b += weight * rg[2];
+            if (T < T_thresh) break;
+            sg++; rg += 3; dl += 2;
+            step++;
+        }
+        survive = !(step < n_step);
+        if (survive) rays_t[index] = t;
+        else rays_alive[n] = -1;
+        weights_sum[index] = weight_sum;
+        depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+    const unsigned long long mask = __ballot(survive);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < kLoopBlock / kWave; w++) s += wave_cnt[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+// stable compaction (renderer.py:258) + loop control (renderer.py:242-249, 262) for the next iteration
+__global__ void __launch_bounds__(kLoopBlock)
+k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps,
+               const int32_t *__restrict__ rays_in, int32_t *__restrict__ rays_out,
+               const uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t red[kLoopBlock / kWave];
+    __shared__ uint32_t wave_off[kLoopBlock / kWave];
+    if (!st[4]) {
+        if (blockIdx.x == 0 && threadIdx.x < 8) st_next[threadIdx.x] = st[threadIdx.x];
+        return;
+    }
+    const uint32_t n_alive = (uint32_t)st[0];
+    const uint32_t n_blocks = (n_alive + kLoopBlock - 1) / kLoopBlock;
+    if (blockIdx.x >= n_blocks) return;
+
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kLoopBlock) part += block_counts[b];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    uint32_t offset = 0;
+    for (int w = 0; w < kLoopBlock / kWave; w++) offset += red[w];
+
+    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
+    const int32_t v = (n < n_alive) ? rays_in[n] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t within = ballot_prefix(mask);
+    if ((threadIdx.x & 63) == 0) wave_off[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kLoopBlock / kWave; w++) {
+        const uint32_t cw = wave_off[w];
+        before += (w < (threadIdx.x >> 6)) ? cw : 0u;
+        total += cw;
+    }
+    if (keep) rays_out[offset + before + within] = v;
+    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0)
+        next_state(st_next, N, offset + total, (uint32_t)st[1] + (uint32_t)st[2], max_steps);
+}
+
+// ==========================================================================================================
+// Torso pass (nerf/renderer.py:269-299, nerf/network.py:188-219) and final blend (renderer.py:306-311)
+//
+// Packed torso image: deform L0 (21 steps, freq(x) part) | deform L1 (32 steps) | deform L2 VALU [2][2][32]
+//                     | torso L0 (37 steps x 64: grid 16 + freq 21, 32 rows) | torso L1 (16 steps x 64)
+//                     | torso L2 VALU [4][2][16] | raw broadcast columns for the bias: def [64][54+ind], tor [32][54+ind]
+constexpr int kTStep32 = 64;  // floats per MFMA step of a 32-row layer ([2 h][32 j])
+constexpr int TOFF_D0 = 0;
+constexpr int TOFF_D1 = TOFF_D0 + 21 * kStep;
+constexpr int TOFF_D2 = TOFF_D1 + 32 * kStep;
+constexpr int TOFF_T0 = TOFF_D2 + 128;
+constexpr int TOFF_T1 = TOFF_T0 + 37 * kTStep32;
+constexpr int TOFF_T2 = TOFF_T1 + 16 * kTStep32;
+constexpr int kTorsoPacked = TOFF_T2 + 128;  // 10320 floats
+constexpr int kTorsoBias = 96;               // deform 64 | torso 32
+
+struct RawT {
+    const float *def_w0, *def_w1, *def_w2, *tor_w0, *tor_w1, *tor_w2;
+    uint32_t ind_dim;
+};
+
+// k index of a 32-wide hidden vector held in one accumulator row tile
+__host__ __device__ constexpr int kmap32(int s, int h) { return rowmap(s & 15, h); }
+
+__global__ void __launch_bounds__(256) k_pack_torso(RawT w, float *__restrict__ packed) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kTorsoPacked) return;
+    const int ldD0 = 96 + (int)w.ind_dim, ldT0 = 128 + (int)w.ind_dim;
+    float v;
+    if (e < TOFF_D1) {  // deform L0: k = 2s + h over freq(x) (42)
+        const int q = e - TOFF_D0, s = q / kStep, rem = q % kStep, h = rem / 64, j = (rem % 64) / 2, rt = rem % 2;
+        v = w.def_w0[(32 * rt + j) * ldD0 + 2 * s + h];
+    } else if (e < TOFF_D2) {
+        const int q = e - TOFF_D1, s = q / kStep, rem = q % kStep, h = rem / 64, j = (rem % 64) / 2, rt = rem % 2;
+        v = w.def_w1[(32 * rt + j) * 64 + kmap(s, h)];
+    } else if (e < TOFF_T0) {
+        const int q0 = e - TOFF_D2, o = q0 / 64, h = (q0 % 64) / 32, q = q0 % 32;
+        v = w.def_w2[o * 64 + 32 * (q >> 4) + rowmap(q & 15, h)];
+    } else if (e < TOFF_T1) {  // torso L0: steps 0..15 grid (cols 0..31), 16..36 freq(x) (cols 32..73)
+        const int q = e - TOFF_T0, s = q / kTStep32, rem = q % kTStep32, h = rem / 32, j = rem % 32;
+        v = w.tor_w0[j * ldT0 + 2 * s + h];
+    } else if (e < TOFF_T2) {
+        const int q = e - TOFF_T1, s = q / kTStep32, rem = q % kTStep32, h = rem / 32, j = rem % 32;
+        v = w.tor_w1[j * 32 + kmap32(s, h)];
+    } else {
+        const int q0 = e - TOFF_T2, o = q0 / 32, h = (q0 % 32) / 16, r = q0 % 16;
+        v = w.tor_w2[o * 32 + rowmap(r, h)];
+    }
+    packed[e] = v;
+}
+
+struct TorsoParams {
+    const float *bg_coords;
+    uint32_t N;
+    const float *density_grid;
+    uint32_t G;
+    float thresh;
+    const float *poses6, *ind_code;
+    float shrink;
+    RawT w;
+    const float *packed;
+    GridArgs gt;
+    const float *bg_in;
+    float *bg_out, *alpha_out, *deform_out;
+};
+
+// F.grid_sample(bilinear, zeros, align_corners=True) of the [G,G] torso grid at (gx, gy) (renderer.py:282)
+__device__ __forceinline__ float sample_torso_grid(const float *__restrict__ img, uint32_t G, float gx, float gy) {
+    const float ix = ((gx + 1.f) / 2) * (float)(G - 1);
+    const float iy = ((gy + 1.f) / 2) * (float)(G - 1);
+    const float ix_nw = floorf(ix), iy_nw = floorf(iy);
+    const float ix_se = ix_nw + 1, iy_se = iy_nw + 1;
+    const float nw = (ix_se - ix) * (iy_se - iy), ne = (ix - ix_nw) * (iy_se - iy);
+    const float sw = (ix_se - ix) * (iy - iy_nw), se = (ix - ix_nw) * (iy - iy_nw);
+    const int x0 = (int)ix_nw, y0 = (int)iy_nw, x1 = x0 + 1, y1 = y0 + 1;
+    const int g = (int)G;
+    float out = 0.0f;
+    if (x0 >= 0 && x0 < g && y0 >= 0 && y0 < g) out += img[y0 * g + x0] * nw;
+    if (x1 >= 0 && x1 < g && y0 >= 0 && y0 < g) out += img[y0 * g + x1] * ne;
+    if (x0 >= 0 && x0 < g && y1 >= 0 && y1 < g) out += img[y1 * g + x0] * sw;
+    if (x1 >= 0 && x1 < g && y1 >= 0 && y1 < g) out += img[y1 * g + x1] * se;
+    return out;
+}
+
+template <typename TT>
+__global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kTorsoPacked + kTorsoBias + 64];
+    __shared__ LevelLds lvl_t[16];
+    float *bias_def = lds + kTorsoPacked, *bias_tor = bias_def + 64, *enc_pose = bias_tor + 32;
+    if (threadIdx.x >= 64 && threadIdx.x < 80) {
+        const int t = threadIdx.x - 64;
+        const uint32_t o = (uint32_t)p.gt.offsets[t];
+        lvl_t[t] = LevelLds{p.gt.lc.scale[t], p.gt.lc.resolution[t], o, (uint32_t)p.gt.offsets[t + 1] - o};
+    }
+
+    for (int i = threadIdx.x; i < kTorsoPacked / 4; i += kFusedThreads)
+        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
+    // enc_pose = freq(poses6, deg 4) -> 54 values (network.py:197), same layout as k_freq_forward
+    if (threadIdx.x < 54) {
+        const int c = threadIdx.x;
+        float v;
+        if (c < 6) v = p.poses6[c];
+        else {
+            const int col = c / 6 - 1, d = c % 6, f = col / 2;
+            const float a = scalbnf(p.poses6[d], f);
+            v = (col & 1) ? sinf(a + 3.141592653589793f / 2) : sinf(a);
+        }
+        enc_pose[c] = v;
+    }
+    __syncthreads();
+    // broadcast columns: deform [42 .. 96+ind), torso [74 .. 128+ind)  (network.py:201, 212)
+    if (threadIdx.x < 96) {
+        const int t = threadIdx.x;
+        const bool is_def = t < 64;
+        const int row = is_def ? t : t - 64;
+        const int ld = (is_def ? 96 : 128) + (int)p.w.ind_dim;
+        const float *r = (is_def ? p.w.def_w0 : p.w.tor_w0) + row * ld + (is_def ? 42 : 74);
+        float acc = 0.0f;
+        for (int k = 0; k < 54; k++) acc += r[k] * enc_pose[k];
+        for (uint32_t c = 0; c < p.w.ind_dim; c++) acc += r[54 + c] * p.ind_code[c];
+        (is_def ? bias_def : bias_tor)[row] = acc;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int lane_off = h * 64 + j * 2, lane_off32 = h * 32 + j;
+    const uint32_t n_tiles = (p.N + 63u) >> 6;
+
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+        const uint32_t px = tile * 64 + lane;
+        const bool in_range = px < p.N;
+        float cx = 0.0f, cy = 0.0f;
+        bool on = false;
+        if (in_range) {
+            cx = p.bg_coords[2 * (size_t)px]; cy = p.bg_coords[2 * (size_t)px + 1];
+            on = sample_torso_grid(p.density_grid, p.G, cx, cy) > p.thresh;
+        }
+        float bgc[3] = {1.0f, 1.0f, 1.0f};
+        if (in_range && p.bg_in) { bgc[0] = p.bg_in[3 * (size_t)px]; bgc[1] = p.bg_in[3 * (size_t)px + 1]; bgc[2] = p.bg_in[3 * (size_t)px + 2]; }
+        if (__ballot(on) == 0ull) {  // no torso pixel in this tile: background passes through
+            if (in_range) {
+                p.bg_out[3 * (size_t)px] = bgc[0]; p.bg_out[3 * (size_t)px + 1] = bgc[1]; p.bg_out[3 * (size_t)px + 2] = bgc[2];
+                if (p.alpha_out) p.alpha_out[px] = 0.0f;
+                if (p.deform_out) { p.deform_out[2 * (size_t)px] = 0.0f; p.deform_out[2 * (size_t)px + 1] = 0.0f; }
+            }
+            continue;
+        }
+        // x = x * torso_shrink; enc_x = freq(x, deg 10) (network.py:194,198): [x, sin(2^f x), cos(2^f x)]_f
+        const float x0 = cx * p.shrink, x1 = cy * p.shrink;
+        float bq[2][21];
+        {
+            float fq[42];
+            fq[0] = x0; fq[1] = x1;
+#pragma unroll
+            for (int f = 0; f < 10; f++) {
+                const float a0 = scalbnf(x0, f), a1 = scalbnf(x1, f);
+                fq[2 + 4 * f + 0] = on ? sinf(a0) : 0.0f;
+                fq[2 + 4 * f + 1] = on ? sinf(a1) : 0.0f;
+                fq[2 + 4 * f + 2] = on ? sinf(a0 + 3.141592653589793f / 2) : 0.0f;
+                fq[2 + 4 * f + 3] = on ? sinf(a1 + 3.141592653589793f / 2) : 0.0f;
+            }
+            if (!on) { fq[0] = 0.0f; fq[1] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 21; s++) to_b_operands(fq[2 * s], fq[2 * s + 1], bq[0][s], bq[1][s]);
+        }
+        // deform net 104 -> 64 -> 64 -> 2
+        Acc a0, a1;
+        acc_bias(a0, bias_def, h);
+#pragma unroll
+        for (int s = 0; s < 21; s++) step64(a0, lds + TOFF_D0, s, lane_off, bq[0][s], bq[1][s]);
+        acc_relu(a0);
+        acc_zero(a1);
+        layer_from_acc(a1, a0, lds + TOFF_D1, lane_off);
+        acc_relu(a1);
+        float dxy[2];
+        {
+            float part[2][2];
+            valu_out<2>(a1, lds + TOFF_D2, h, part);
+            dxy[0] = h ? part[1][0] : part[0][0];
+            dxy[1] = h ? part[1][1] : part[0][1];
+        }
+        // x = clamp(x + dx, -1, 1); torso grid (bound = 1)
+        float bg_[2][16];
+        {
+            float in[2] = {(fminf(fmaxf(x0 + dxy[0], -1.0f), 1.0f) + 1.0f) / 2.0f,
+                           (fminf(fmaxf(x1 + dxy[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
+            const bool ok = on && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
+#pragma unroll
+            for (int l = 0; l < 16; l++) {
+                float f0, f1;
+                level_features<TT, 2>(p.gt.table, lvl_t[l], p.gt.gridtype, in, ok, f0, f1);
+                to_b_operands(f0, f1, bg_[0][l], bg_[1][l]);
+            }
+        }
+        // torso net 136 -> 32 -> 32 -> 4 : a single 32-row tile
+        f32x16 t0[2], t1[2];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias_tor + 8 * g + 4 * h);
+            t0[0][4 * g] = b.x; t0[0][4 * g + 1] = b.y; t0[0][4 * g + 2] = b.z; t0[0][4 * g + 3] = b.w;
+            t0[1][4 * g] = b.x; t0[1][4 * g + 1] = b.y; t0[1][4 * g + 2] = b.z; t0[1][4 * g + 3] = b.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const float wv = lds[TOFF_T0 + s * kTStep32 + lane_off32];
+            t0[0] = mfma32(wv, bg_[0][s], t0[0]); t0[1] = mfma32(wv, bg_[1][s], t0[1]);
+        }
+#pragma unroll
+        for (int s = 0; s < 21; s++) {
+            const float wv = lds[TOFF_T0 + (16 + s) * kTStep32 + lane_off32];
+            t0[0] = mfma32(wv, bq[0][s], t0[0]); t0[1] = mfma32(wv, bq[1][s], t0[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) { t0[0][r] = fmaxf(t0[0][r], 0.0f); t0[1][r] = fmaxf(t0[1][r], 0.0f); t1[0][r] = 0.0f; t1[1][r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const float wv = lds[TOFF_T1 + s * kTStep32 + lane_off32];
+            t1[0] = mfma32(wv, t0[0][s], t1[0]); t1[1] = mfma32(wv, t0[1][s], t1[1]);
+        }
+        float o4[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float p0 = 0.0f, p1 = 0.0f;
+            const float *wo = lds + TOFF_T2 + (o * 2 + h) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                p0 = __builtin_fmaf(fmaxf(t1[0][r], 0.0f), wo[r], p0);
+                p1 = __builtin_fmaf(fmaxf(t1[1][r], 0.0f), wo[r], p1);
+            }
+            p0 += __shfl_xor(p0, 32, 64);
+            p1 += __shfl_xor(p1, 32, 64);
+            o4[o] = h ? p1 : p0;
+        }
+        if (in_range) {
+            float alpha = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
+            if (on) {
+                alpha = 1.0f / (1.0f + expf(-o4[0]));
+#pragma unroll
+                for (int c = 0; c < 3; c++) col[c] = 1.0f / (1.0f + expf(-o4[1 + c]));
+            }
+            // bg = torso_color * alpha + bg * (1 - alpha)  (renderer.py:299)
+#pragma unroll
+            for (int c = 0; c < 3; c++) p.bg_out[3 * (size_t)px + c] = col[c] * alpha + bgc[c] * (1 - alpha);
+            if (p.alpha_out) p.alpha_out[px] = alpha;
+            if (p.deform_out) { p.deform_out[2 * (size_t)px] = on ? dxy[0] : 0.0f; p.deform_out[2 * (size_t)px + 1] = on ? dxy[1] : 0.0f; }
+        }
+    }
+}
+
+// renderer.py:306-311
+__global__ void __launch_bounds__(256)
+k_blend(float *__restrict__ image, const float *__restrict__ weights_sum, const float *__restrict__ bg,
+        float *__restrict__ depth, const float *__restrict__ nears, const float *__restrict__ fars, uint32_t N,
+        uint8_t *__restrict__ u8) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float w = 1 - weights_sum[n];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float b = bg ? bg[3 * (size_t)n + c] : 1.0f;
+        float v = image[3 * (size_t)n + c] + w * b;
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        image[3 * (size_t)n + c] = v;
+        if (u8) u8[3 * (size_t)n + c] = (uint8_t)(v * 255.0f);
+    }
+    const float dd = depth[n] - nears[n];
+    depth[n] = fmaxf(dd, 0.0f) / (fars[n] - nears[n]);
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------------
+static int check_grid(const rn_grid_t *g, uint32_t D, const char *name) {
+    RN_REQUIRE(g && g->embeddings && g->offsets, "%s: null grid", name);
+    RN_REQUIRE(g->D == D && g->L == 16, "%s: fused path needs D=%u, L=16 (got D=%u L=%u)", name, D, g->D, g->L);
+    RN_REQUIRE(g->gridtype <= 1 && (g->dtype == RN_F32 || g->dtype == RN_F16), "%s: bad gridtype/dtype", name);
+    RN_REQUIRE(((uintptr_t)g->embeddings & 7u) == 0, "%s: table must be 8-byte aligned", name);
+    return RN_OK;
+}
+static GridArgs grid_args(const rn_grid_t *g) {
+    return GridArgs{g->embeddings, g->offsets, make_level_consts(g->L, g->S, g->H), g->gridtype};
+}
+static RawW raw_w(const rn_nerf_weights_t *w) {
+    return RawW{w->amb_w0, w->amb_w1, w->amb_w2, w->sig_w0, w->sig_w1, w->sig_w2, w->col_w0, w->col_w1,
+                w->audio_dim, w->has_eye, w->ind_dim};
+}
+static int check_w(const rn_nerf_weights_t *w) {
+    RN_REQUIRE(w && w->amb_w0 && w->amb_w1 && w->amb_w2 && w->sig_w0 && w->sig_w1 && w->sig_w2 && w->col_w0 && w->col_w1,
+               "nerf weights: null pointer");
+    RN_REQUIRE(w->has_eye <= 1 && w->audio_dim <= 1024 && w->ind_dim <= 1024, "nerf weights: bad dims");
+    return RN_OK;
+}
+
+static int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <typename TX, typename TW>
+static void launch_fused(const FusedParams &p, hipStream_t s) {
+    const uint32_t n_tiles = (p.M + 63u) >> 6;
+    uint32_t blocks = div_up(n_tiles, kWavesPerBlock);
+    const uint32_t cap = (uint32_t)num_cus();  // one persistent workgroup per CU (96.5 KB of LDS each)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_nerf_fused<TX, TW>), dim3(blocks), dim3(kFusedThreads), 0, s, p);
+}
+
+static int run_fused(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
+                     const rn_grid_t *gx, const rn_grid_t *gw, const float *packed, const float *bias, float bound,
+                     float *sigmas, float *rgbs, float *ambient, hipStream_t s) {
+    FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient};
+    if (gx->dtype == RN_F32 && gw->dtype == RN_F32) launch_fused<float, float>(p, s);
+    else if (gx->dtype == RN_F16 && gw->dtype == RN_F16) launch_fused<__half, __half>(p, s);
+    else if (gx->dtype == RN_F32) launch_fused<float, __half>(p, s);
+    else launch_fused<__half, float>(p, s);
+    return RN_OK;
+}
+
+}  // namespace rn
+
+using namespace rn;
+
+extern "C" {
+
+size_t rn_nerf_packed_floats(void) { return (size_t)kPacked; }
+size_t rn_nerf_bias_floats(void) { return (size_t)kBias; }
+
+int rn_nerf_pack_weights(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(packed && ((uintptr_t)packed & 15u) == 0, "nerf_pack_weights: packed must be 16-byte aligned");
+    hipLaunchKernelGGL(k_pack_nerf, dim3(div_up(kPacked, 256)), dim3(256), 0, as_stream(stream), raw_w(w), packed);
+    return check_launch("nerf_pack_weights");
+}
+
+int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
+                       float *bias, rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(bias, "nerf_frame_bias: null output");
+    RN_REQUIRE(enc_a || w->audio_dim == 0, "nerf_frame_bias: enc_a is required");
+    RN_REQUIRE(eye || !w->has_eye, "nerf_frame_bias: eye is required when has_eye");
+    RN_REQUIRE(ind_code || w->ind_dim == 0, "nerf_frame_bias: ind_code is required when ind_dim > 0");
+    hipLaunchKernelGGL(k_frame_bias, dim3(1), dim3(kBias), 0, as_stream(stream), raw_w(w), enc_a, eye, ind_code, bias);
+    return check_launch("nerf_frame_bias");
+}
+
+int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
+                          const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed, const float *bias,
+                          float bound, float *sigmas, float *rgbs, float *ambient, rn_stream_t stream) {
+    if (M == 0) return RN_OK;
+    RN_REQUIRE(xyzs && dirs && packed && bias && sigmas && rgbs, "nerf_fused_forward: null pointer");
+    RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "nerf_fused_forward: packed must be 16-byte aligned");
+    if (int rc = check_grid(grid_xyz, 3, "nerf_fused_forward(xyz grid)")) return rc;
+    if (int rc = check_grid(grid_amb, 2, "nerf_fused_forward(ambient grid)")) return rc;
+    run_fused(xyzs, dirs, deltas, M, m_dev, grid_xyz, grid_amb, packed, bias, bound, sigmas, rgbs, ambient, as_stream(stream));
+    return check_launch("nerf_fused_forward");
+}
+
+static int check_head(const rn_head_t *h) {
+    RN_REQUIRE(h, "head: null descriptor");
+    RN_REQUIRE(h->rays_o && h->rays_d && h->aabb && h->bitfield && h->nears && h->fars && h->weights_sum && h->depth &&
+                   h->image && h->rays_alive_a && h->rays_alive_b && h->rays_t && h->xyzs && h->dirs && h->deltas &&
+                   h->sigmas && h->rgbs && h->state && h->block_counts,
+               "head: null pointer");
+    RN_REQUIRE(h->N >= 1 && h->max_steps >= 1 && h->cascade >= 1 && h->cascade <= 16 && h->grid_size >= 1, "head: bad sizes");
+    return RN_OK;
+}
+
+int rn_head_begin(const rn_head_t *h, rn_stream_t stream) {
+    if (int rc = check_head(h)) return rc;
+    hipLaunchKernelGGL(k_head_begin, dim3(div_up(h->N, kLoopBlock)), dim3(kLoopBlock), 0, as_stream(stream), h->rays_o,
+                       h->rays_d, h->aabb, h->N, h->min_near, h->max_steps, h->nears, h->fars, h->weights_sum, h->depth,
+                       h->image, h->rays_alive_a, h->rays_t, h->state);
+    return check_launch("head_begin");
+}
+
+int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
+                    const float *bias, uint32_t first_iter, uint32_t n_iters, rn_stream_t stream) {
+    if (int rc = check_head(h)) return rc;
+    RN_REQUIRE(packed && bias && ((uintptr_t)packed & 15u) == 0, "head_iterate: packed/bias");
+    if (int rc = check_grid(grid_xyz, 3, "head_iterate(xyz grid)")) return rc;
+    if (int rc = check_grid(grid_amb, 2, "head_iterate(ambient grid)")) return rc;
+    hipStream_t s = as_stream(stream);
+    const dim3 rgrid(div_up(h->N, kLoopBlock)), rblock(kLoopBlock);
+    for (uint32_t it = first_iter; it < first_iter + n_iters; it++) {
+        int32_t *st = h->state + (it & 1u) * 8, *st_next = h->state + ((it + 1) & 1u) * 8;
+        int32_t *alive = (it & 1u) ? h->rays_alive_b : h->rays_alive_a;
+        int32_t *alive_next = (it & 1u) ? h->rays_alive_a : h->rays_alive_b;
+        hipLaunchKernelGGL(k_head_march, rgrid, rblock, 0, s, st, alive, h->rays_t, h->rays_o, h->rays_d, h->bound,
+                           h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
+                           h->deltas, h->state);
+        run_fused(h->xyzs, h->dirs, h->deltas, h->N, st + 3, grid_xyz, grid_amb, packed, bias, h->bound, h->sigmas, h->rgbs,
+                  nullptr, s);
+        hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
+                           h->deltas, h->weights_sum, h->depth, h->image, h->block_counts);
+        hipLaunchKernelGGL(k_head_compact, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
+                           h->block_counts);
+    }
+    return check_launch("head_iterate");
+}
+
+size_t rn_torso_packed_floats(void) { return (size_t)kTorsoPacked; }
+
+int rn_torso_pack_weights(const rn_torso_weights_t *w, float *packed, rn_stream_t stream) {
+    RN_REQUIRE(w && w->def_w0 && w->def_w1 && w->def_w2 && w->tor_w0 && w->tor_w1 && w->tor_w2 && packed,
+               "torso_pack_weights: null pointer");
+    RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "torso_pack_weights: packed must be 16-byte aligned");
+    RawT r{w->def_w0, w->def_w1, w->def_w2, w->tor_w0, w->tor_w1, w->tor_w2, w->ind_dim};
+    hipLaunchKernelGGL(k_pack_torso, dim3(div_up(kTorsoPacked, 256)), dim3(256), 0, as_stream(stream), r, packed);
+    return check_launch("torso_pack_weights");
+}
+
+int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size, float thresh,
+                   const float *poses6, const float *ind_code, float torso_shrink, const rn_torso_weights_t *w,
+                   const float *packed, const rn_grid_t *grid_torso, const float *bg_in, float *bg_out,
+                   float *torso_alpha, float *deform, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
+    RN_REQUIRE(bg_coords && density_grid_torso && poses6 && w && packed && bg_out, "torso_fused: null pointer");
+    RN_REQUIRE(ind_code || w->ind_dim == 0, "torso_fused: ind_code required when ind_dim > 0");
+    RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "torso_fused: packed must be 16-byte aligned");
+    if (int rc = check_grid(grid_torso, 2, "torso_fused(torso grid)")) return rc;
+    RawT r{w->def_w0, w->def_w1, w->def_w2, w->tor_w0, w->tor_w1, w->tor_w2, w->ind_dim};
+    TorsoParams p{bg_coords, N, density_grid_torso, grid_size, thresh, poses6, ind_code, torso_shrink, r, packed,
+                  grid_args(grid_torso), bg_in, bg_out, torso_alpha, deform};
+    uint32_t blocks = div_up((N + 63u) >> 6, kWavesPerBlock);
+    const uint32_t cap = (uint32_t)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    if (grid_torso->dtype == RN_F32) hipLaunchKernelGGL((k_torso_fused<float>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_torso_fused<__half>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
+    return check_launch("torso_fused");
+}
+
+int rn_blend_frame(float *image, const float *weights_sum, const float *bg, float *depth, const float *nears,
+                   const float *fars, uint32_t N, uint8_t *image_u8, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
+    RN_REQUIRE(image && weights_sum && depth && nears && fars, "blend_frame: null pointer");
+    hipLaunchKernelGGL(k_blend, dim3(div_up(N, 256)), dim3(256), 0, as_stream(stream), image, weights_sum, bg, depth, nears,
+                       fars, N, image_u8);
+    return check_launch("blend_frame");
+}
+
+}  // extern "C"

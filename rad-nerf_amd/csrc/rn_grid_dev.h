@@ -84,6 +84,10 @@ __device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, bool align_corne
         }
     }
     if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
+    // index % hashmap_size without the ~30-instruction integer division on the two cases that occur in
+    // practice: capped levels have a power-of-two row count, dense levels have index < row count.
+    if ((hashmap_size & (hashmap_size - 1u)) == 0u) return index & (hashmap_size - 1u);
+    if (index < hashmap_size) return index;
     return index % hashmap_size;
 }
 

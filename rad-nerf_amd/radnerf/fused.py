@@ -1,0 +1,303 @@
+"""Fused inference engine: NeRFRenderer.run_cuda's inference branch on the MI355X-native C ABI
+(include/radnerf_fused.h).
+
+Per frame the host enqueues, on torch's current stream and without reading anything back first:
+
+    rn_nerf_frame_bias   broadcast inputs (audio code, eye, individual code) -> 3 x 64 bias values
+    rn_head_begin        near/far + loop state
+    rn_head_iterate      K x {march, fused network (grid gathers + fp32 MFMA MLPs), composite, stable compaction}
+    rn_torso_fused       torso occupancy test + deformation / torso MLPs + blend over the background
+    (read 1 int)         "does the loop want more iterations?" -- overlapped with the torso kernel; K adapts
+    rn_blend_frame       image + (1 - weights_sum) * bg, clamp, depth normalisation [, uint8]
+
+Results equal the per-operator engine's (same DDA samples, same grid features, fp32 MLPs; parity tests in
+tests/test_gpu_fused.py).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import radnerf_hip as hip
+
+_lib = hip._lib
+_u32, _f32, _i32, _ptr = C.c_uint32, C.c_float, C.c_int, C.c_void_p
+
+
+class GridT(C.Structure):
+    _fields_ = [("embeddings", _ptr), ("offsets", _ptr), ("D", _u32), ("L", _u32), ("H", _u32), ("S", _f32),
+                ("gridtype", _u32), ("dtype", _i32)]
+
+
+class NerfWeightsT(C.Structure):
+    _fields_ = [("amb_w0", _ptr), ("amb_w1", _ptr), ("amb_w2", _ptr), ("sig_w0", _ptr), ("sig_w1", _ptr),
+                ("sig_w2", _ptr), ("col_w0", _ptr), ("col_w1", _ptr), ("audio_dim", _u32), ("has_eye", _u32),
+                ("ind_dim", _u32)]
+
+
+class TorsoWeightsT(C.Structure):
+    _fields_ = [("def_w0", _ptr), ("def_w1", _ptr), ("def_w2", _ptr), ("tor_w0", _ptr), ("tor_w1", _ptr),
+                ("tor_w2", _ptr), ("ind_dim", _u32)]
+
+
+class HeadT(C.Structure):
+    _fields_ = [("rays_o", _ptr), ("rays_d", _ptr), ("N", _u32), ("aabb", _ptr), ("min_near", _f32),
+                ("bitfield", _ptr), ("bound", _f32), ("dt_gamma", _f32), ("max_steps", _u32), ("cascade", _u32),
+                ("grid_size", _u32), ("T_thresh", _f32), ("nears", _ptr), ("fars", _ptr), ("weights_sum", _ptr),
+                ("depth", _ptr), ("image", _ptr), ("rays_alive_a", _ptr), ("rays_alive_b", _ptr), ("rays_t", _ptr),
+                ("xyzs", _ptr), ("dirs", _ptr), ("deltas", _ptr), ("sigmas", _ptr), ("rgbs", _ptr), ("state", _ptr),
+                ("block_counts", _ptr)]
+
+
+RN_HEAD_STATE_INTS = 32
+ST_ACTIVE, ST_ITERS, ST_LIVE, ST_SLOTS = 4, 16, 17, 18
+
+_SIGS = {
+    "rn_nerf_pack_weights": [C.POINTER(NerfWeightsT), _ptr, _ptr],
+    "rn_nerf_frame_bias": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_nerf_fused_forward": [_ptr, _ptr, _ptr, _u32, _ptr, C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _f32, _ptr,
+                              _ptr, _ptr, _ptr],
+    "rn_head_begin": [C.POINTER(HeadT), _ptr],
+    "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, _ptr],
+    "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
+    "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
+                       _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_blend_frame": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr],
+}
+for _n, _a in _SIGS.items():
+    _f = getattr(_lib, _n)
+    _f.argtypes = _a
+    _f.restype = C.c_int
+_lib.rn_nerf_packed_floats.restype = C.c_size_t
+_lib.rn_nerf_bias_floats.restype = C.c_size_t
+_lib.rn_torso_packed_floats.restype = C.c_size_t
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + ["rn_nerf_packed_floats", "rn_nerf_bias_floats", "rn_torso_packed_floats"])
+
+
+def _grid_desc(enc, table):
+    g = GridT()
+    g.embeddings, g.offsets = table.data_ptr(), enc.offsets.data_ptr()
+    g.D, g.L, g.H = enc.input_dim, enc.num_levels, enc.base_resolution
+    g.S = float(np.log2(enc.per_level_scale))
+    g.gridtype = enc.gridtype_id
+    g.dtype = hip.RN_F16 if table.dtype == torch.float16 else hip.RN_F32
+    return g
+
+
+def supported(model):
+    """True when the model has the shape the fused kernels are built for (else: use the 'ops' engine)."""
+    try:
+        ok = (model.encoder.num_levels == 16 and model.encoder.level_dim == 2 and model.encoder.input_dim == 3
+              and model.encoder_ambient.num_levels == 16 and model.encoder_ambient.level_dim == 2
+              and model.encoder_ambient.input_dim == 2 and model.hidden_dim == 64 and model.geo_feat_dim == 64
+              and model.hidden_dim_ambient == 64 and model.hidden_dim_color == 64 and model.num_layers == 3
+              and model.num_layers_ambient == 3 and model.num_layers_color == 2 and model.ambient_dim == 2
+              and model.encoder_dir.degree == 4 and not model.encoder.align_corners and model.encoder.interp_id == 0)
+        if model.torso:
+            ok = ok and (model.torso_encoder.num_levels == 16 and model.torso_encoder.level_dim == 2
+                         and model.torso_deform_net.dim_hidden == 64 and model.torso_net.dim_hidden == 32
+                         and model.torso_deform_in_dim == 42 and model.pose_in_dim == 54)
+        return bool(ok)
+    except AttributeError:
+        return False
+
+
+class FusedState:
+    """Device-side constants + scratch of one model: packed weights (re-packed when parameters change),
+    grid descriptors, per-frame bias block, loop scratch for N rays."""
+
+    def __init__(self, model):
+        if not supported(model):
+            raise RuntimeError("fused engine: unsupported network shape; use engine='ops'")
+        self.model = model
+        self.dev = model.density_bitfield.device
+        self.packed = torch.empty(int(_lib.rn_nerf_packed_floats()), dtype=torch.float32, device=self.dev)
+        self.bias = torch.empty(int(_lib.rn_nerf_bias_floats()), dtype=torch.float32, device=self.dev)
+        self.tpacked = (torch.empty(int(_lib.rn_torso_packed_floats()), dtype=torch.float32, device=self.dev)
+                        if model.torso else None)
+        self._versions = None
+        self._N = 0
+        self.iters_hint = None
+        self._zero_eye = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    # -- weights --------------------------------------------------------------------------------------
+    def _weights(self):
+        m = self.model
+        ws = [l.weight for l in m.ambient_net.net] + [l.weight for l in m.sigma_net.net] + [l.weight for l in m.color_net.net]
+        if m.torso:
+            ws += [l.weight for l in m.torso_deform_net.net] + [l.weight for l in m.torso_net.net]
+        return ws
+
+    def refresh(self):
+        ws = self._weights()
+        tables = [self.model.encoder.embeddings, self.model.encoder_ambient.embeddings]
+        if self.model.torso:
+            tables.append(self.model.torso_encoder.embeddings)
+        versions = tuple((w._version, w.data_ptr()) for w in ws + tables)
+        if versions == self._versions:
+            return
+        m = self.model
+        for w in ws:
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise RuntimeError("fused engine: MLP weights must be contiguous float32")
+        self.nw = NerfWeightsT()
+        (self.nw.amb_w0, self.nw.amb_w1, self.nw.amb_w2, self.nw.sig_w0, self.nw.sig_w1, self.nw.sig_w2, self.nw.col_w0,
+         self.nw.col_w1) = [w.data_ptr() for w in ws[:8]]
+        self.nw.audio_dim, self.nw.has_eye, self.nw.ind_dim = m.audio_dim, int(m.exp_eye), m.individual_dim
+        assert tuple(ws[0].shape) == (64, 32 + m.audio_dim) and tuple(ws[3].shape) == (64, 64 + int(m.exp_eye))
+        assert tuple(ws[5].shape) == (65, 64) and tuple(ws[6].shape) == (64, 80 + m.individual_dim)
+        hip.call("rn_nerf_pack_weights", C.byref(self.nw), hip.ptr(self.packed), hip.stream())
+        if m.torso:
+            self.tw = TorsoWeightsT()
+            (self.tw.def_w0, self.tw.def_w1, self.tw.def_w2, self.tw.tor_w0, self.tw.tor_w1,
+             self.tw.tor_w2) = [w.data_ptr() for w in ws[8:14]]
+            self.tw.ind_dim = m.individual_dim_torso
+            assert tuple(ws[8].shape) == (64, 96 + m.individual_dim_torso) and tuple(ws[11].shape) == (32, 128 + m.individual_dim_torso)
+            hip.call("rn_torso_pack_weights", C.byref(self.tw), hip.ptr(self.tpacked), hip.stream())
+        # tables: fp32 parameters are read in place (fp16 copies are a separate, opt-in mode)
+        self.tables = [hip.aligned(t.detach()) for t in tables]
+        self.gx = _grid_desc(m.encoder, self.tables[0])
+        self.gw = _grid_desc(m.encoder_ambient, self.tables[1])
+        self.gt = _grid_desc(m.torso_encoder, self.tables[2]) if m.torso else None
+        self._versions = versions
+
+    # -- scratch --------------------------------------------------------------------------------------
+    def scratch(self, N):
+        if N == self._N:
+            return
+        d, f32, i32 = self.dev, torch.float32, torch.int32
+        self.nears = torch.empty(N, dtype=f32, device=d)
+        self.fars = torch.empty(N, dtype=f32, device=d)
+        self.rays_alive = torch.empty(2, N, dtype=i32, device=d)
+        self.rays_t = torch.empty(N, dtype=f32, device=d)
+        self.samples = torch.empty(N * 8, dtype=f32, device=d)   # xyzs | dirs | deltas
+        self.sigmas = torch.empty(N, dtype=f32, device=d)
+        self.rgbs = torch.empty(N, 3, dtype=f32, device=d)
+        self.state = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32, device=d)
+        self.block_counts = torch.empty((N + 255) // 256 + 1, dtype=i32, device=d)
+        self.bg = torch.empty(N, 3, dtype=f32, device=d)
+        self.state_host = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32).pin_memory()
+        self._N = N
+
+
+def _state(model):
+    st = getattr(model, "_fused_state", None)
+    if st is None or st.model is not model:
+        st = FusedState(model)
+        object.__setattr__(model, "_fused_state", st)
+    return st
+
+
+def network_forward(model, xyzs, dirs, enc_a, ind_code, eye, deltas=None, want_ambient=True):
+    """NeRFNetwork.forward through the fused kernel: (sigma [M], color [M,3], ambient [M,2])."""
+    st = _state(model)
+    st.refresh()
+    xyzs, dirs = xyzs.contiguous().float(), dirs.contiguous().float()
+    M = xyzs.shape[0]
+    enc_a = enc_a.reshape(-1).contiguous().float()
+    eye_t = eye.reshape(-1).contiguous().float() if eye is not None else st._zero_eye
+    ind = ind_code.detach().reshape(-1).contiguous().float() if ind_code is not None else None
+    hip.call("rn_nerf_frame_bias", C.byref(st.nw), hip.ptr(enc_a), hip.ptr(eye_t), hip.ptr(ind), hip.ptr(st.bias), hip.stream())
+    sigmas = torch.empty(M, dtype=torch.float32, device=xyzs.device)
+    rgbs = torch.empty(M, 3, dtype=torch.float32, device=xyzs.device)
+    ambient = torch.empty(M, 2, dtype=torch.float32, device=xyzs.device) if want_ambient else None
+    if deltas is not None:
+        deltas = deltas.contiguous()
+    hip.call("rn_nerf_fused_forward", hip.ptr(xyzs), hip.ptr(dirs), hip.ptr(deltas), M, None, C.byref(st.gx), C.byref(st.gw),
+             hip.ptr(st.packed), hip.ptr(st.bias), float(model.bound), hip.ptr(sigmas), hip.ptr(rgbs), hip.ptr(ambient),
+             hip.stream())
+    return sigmas, rgbs, ambient
+
+
+def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, ind_code_torso, bg_color, dt_gamma,
+                 max_steps, T_thresh, want_u8=False):
+    """Inference frame: returns dict(image [N,3], depth [N], weights_sum [N], nears, fars[, image_u8])."""
+    st = _state(model)
+    st.refresh()
+    N = rays_o.shape[0]
+    st.scratch(N)
+    dev = rays_o.device
+    s = hip.stream()
+
+    enc_a = enc_a.reshape(-1).contiguous().float()
+    eye_t = eye.reshape(-1).contiguous().float() if eye is not None else st._zero_eye
+    ind = ind_code.detach().reshape(-1).contiguous().float() if ind_code is not None else None
+    hip.call("rn_nerf_frame_bias", C.byref(st.nw), hip.ptr(enc_a), hip.ptr(eye_t), hip.ptr(ind), hip.ptr(st.bias), s)
+
+    weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+
+    h = HeadT()
+    h.rays_o, h.rays_d, h.N = rays_o.data_ptr(), rays_d.data_ptr(), N
+    h.aabb, h.min_near = model.aabb_infer.data_ptr(), float(model.min_near)
+    h.bitfield, h.bound, h.dt_gamma = model.density_bitfield.data_ptr(), float(model.bound), float(dt_gamma)
+    h.max_steps, h.cascade, h.grid_size, h.T_thresh = int(max_steps), int(model.cascade), int(model.grid_size), float(T_thresh)
+    h.nears, h.fars = st.nears.data_ptr(), st.fars.data_ptr()
+    h.weights_sum, h.depth, h.image = weights_sum.data_ptr(), depth.data_ptr(), image.data_ptr()
+    h.rays_alive_a, h.rays_alive_b = st.rays_alive[0].data_ptr(), st.rays_alive[1].data_ptr()
+    h.rays_t = st.rays_t.data_ptr()
+    h.xyzs = st.samples.data_ptr()
+    h.dirs = st.samples.data_ptr() + N * 3 * 4
+    h.deltas = st.samples.data_ptr() + N * 6 * 4
+    h.sigmas, h.rgbs = st.sigmas.data_ptr(), st.rgbs.data_ptr()
+    h.state, h.block_counts = st.state.data_ptr(), st.block_counts.data_ptr()
+
+    hip.call("rn_head_begin", C.byref(h), s)
+    k = min(int(max_steps), st.iters_hint + 1) if st.iters_hint else int(max_steps)
+    hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0, k, s)
+    st.state_host.copy_(st.state, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+
+    # torso layer over the background (independent of the head loop: runs while the host reads the loop state)
+    bg_in = None
+    if torch.is_tensor(bg_color):
+        bg_in = bg_color.reshape(-1, 3).contiguous().float()
+        if bg_in.shape[0] != N:
+            bg_in = bg_in.expand(N, 3).contiguous()
+    elif bg_color is not None and float(bg_color) != 1.0:
+        bg_in = torch.full((N, 3), float(bg_color), dtype=torch.float32, device=dev)
+    results = {}
+    bg_final = bg_in
+    if model.torso:
+        thresh = min(model.density_thresh_torso, model.mean_density_torso)
+        ict = ind_code_torso.detach().reshape(-1).contiguous().float() if ind_code_torso is not None else None
+        poses = poses.reshape(-1).contiguous().float()
+        bg_coords = bg_coords.contiguous().float()
+        talpha = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        hip.call("rn_torso_fused", hip.ptr(bg_coords), N, hip.ptr(model.density_grid_torso), int(model.grid_size),
+                 float(thresh), hip.ptr(poses), hip.ptr(ict), float(model.opt.torso_shrink), C.byref(st.tw),
+                 hip.ptr(st.tpacked), C.byref(st.gt), hip.ptr(bg_in), hip.ptr(st.bg), hip.ptr(talpha), None, s)
+        bg_final = st.bg
+        results["torso_alpha"] = talpha
+        results["torso_color"] = st.bg
+
+    # loop control: did K iterations finish the loop?  (one pinned int read, overlapped with the torso kernel)
+    ev.synchronize()
+    done = k
+    while True:
+        bank = (done & 1) * 8
+        if int(st.state_host[bank + ST_ACTIVE]) == 0 or done >= int(max_steps):
+            break
+        more = int(max_steps) - done
+        hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), done,
+                 more, s)
+        done += more
+        st.state_host.copy_(st.state, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    iters = int(st.state_host[ST_ITERS])
+    st.iters_hint = max(iters, 1)
+    model.last_stats = {"iterations": iters, "live_samples": int(st.state_host[ST_LIVE]),
+                        "sample_slots": int(st.state_host[ST_SLOTS]), "enqueued_iterations": done}
+
+    u8 = torch.empty(N, 3, dtype=torch.uint8, device=dev) if want_u8 else None
+    hip.call("rn_blend_frame", hip.ptr(image), hip.ptr(weights_sum), hip.ptr(bg_final), hip.ptr(depth), hip.ptr(st.nears),
+             hip.ptr(st.fars), N, hip.ptr(u8), s)
+    results.update(image=image, depth=depth, weights_sum=weights_sum, nears=st.nears, fars=st.fars)
+    if want_u8:
+        results["image_u8"] = u8
+    return results

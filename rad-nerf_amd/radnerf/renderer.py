@@ -159,6 +159,21 @@ class NeRFRenderer(nn.Module):
         N, device = rays_o.shape[0], rays_o.device
         results = {}
 
+        if not self.training and self.engine == "fused" and not perturb:
+            # MI355X path: the whole frame through the fused C ABI (radnerf/fused.py)
+            from . import fused
+            enc_a = self._audio_code(auds)
+            ind_code = self.individual_codes[0] if self.individual_dim > 0 else None
+            ind_code_torso = (self.individual_codes_torso[0] if (self.torso and self.individual_dim_torso > 0) else None)
+            out = fused.render_frame(self, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, ind_code_torso, bg_color,
+                                     dt_gamma, max_steps, T_thresh, want_u8=kwargs.get("want_u8", False))
+            results["image"] = out["image"].view(*prefix, 3)
+            results["depth"] = out["depth"].view(*prefix)
+            for key in ("torso_alpha", "torso_color", "image_u8"):
+                if key in out:
+                    results[key] = out[key]
+            return results
+
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer,
                                                      self.min_near)
         nears, fars = nears.detach(), fars.detach()
@@ -185,10 +200,6 @@ class NeRFRenderer(nn.Module):
                                                                                       deltas, rays)
             results["weights_sum"] = weights_sum
             results["ambient"] = ambient_sum
-        elif self.engine == "fused":
-            from . import fused
-            weights_sum, depth, image = fused.march_loop(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye,
-                                                         perturb, dt_gamma, max_steps, T_thresh)
         else:
             weights_sum, depth, image = self._march_loop_ops(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb,
                                                              dt_gamma, max_steps, T_thresh)

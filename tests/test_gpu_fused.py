@@ -1,0 +1,161 @@
+"""GPU parity of the MI355X-native fused path (include/radnerf_fused.h) against the oracle and against the
+per-operator engine.
+
+Tolerances (fp32 everywhere; differences are summation order inside the MFMA tiles / folded bias vectors and
+expf/tanhf implementations): per-sample sigma rel 2e-4, rgb / ambient abs 2e-5; frame |dRGB| <= 2e-3
+(north-star bar; measured ~1e-6), integer loop statistics (iterations, live samples) exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(size, engine, n_frames=8, **kw):
+    from radnerf.scene import SyntheticScene, default_opt
+    return SyntheticScene(H=size, W=size, n_frames=n_frames, device="cuda", opt=default_opt(engine=engine, **kw))
+
+
+def test_symbols_of_fused_header_are_exported(hiplib):
+    from radnerf import fused
+    for name in fused.exported_symbols():
+        assert hasattr(hiplib._lib, name), name
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 5000, 100003])
+def test_fused_network_matches_oracle(po, hiplib, M):
+    from radnerf import fused
+    scene = _scene(16, "fused")
+    m = scene.model
+    rng = np.random.default_rng(M)
+    x = rng.uniform(-0.7, 0.7, (M, 3)).astype(np.float32)
+    if M > 10:
+        x[3] = (1.5, 0.0, 0.0)   # outside [-bound, bound] -> enc_x = 0
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    enc_a = rng.standard_normal((1, 64)).astype(np.float32)
+    eye = np.array([[0.25]], np.float32)
+    c = m.individual_codes[0].detach()
+    with torch.no_grad():
+        sigma, color, amb = fused.network_forward(m, torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(),
+                                                  torch.from_numpy(enc_a).cuda(), c, torch.from_numpy(eye).cuda())
+    om = po.model_from_module(m)
+    es, ec, ea = po.nerf_forward(om, x, d, enc_a, c.cpu().numpy(), eye)
+    np.testing.assert_allclose(amb.cpu().numpy(), ea, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), es, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(color.cpu().numpy(), ec, rtol=0, atol=2e-5)
+
+
+def test_fused_network_skips_dead_slots(po, hiplib):
+    from radnerf import fused
+    scene = _scene(16, "fused")
+    m = scene.model
+    rng = np.random.default_rng(5)
+    M = 1000
+    x = rng.uniform(-0.5, 0.5, (M, 3)).astype(np.float32)
+    d = np.tile(np.array([[0.0, -1.0, 0.0]], np.float32), (M, 1))
+    deltas = np.stack([np.full(M, 0.027), np.full(M, 3.0)], 1).astype(np.float32)
+    dead = rng.uniform(size=M) < 0.5
+    dead[64:192] = True  # two whole wave tiles dead
+    deltas[dead] = 0
+    enc_a = rng.standard_normal((1, 64)).astype(np.float32)
+    eye = np.array([[0.25]], np.float32)
+    c = m.individual_codes[0].detach()
+    with torch.no_grad():
+        sigma, color, _ = fused.network_forward(m, torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(),
+                                                torch.from_numpy(enc_a).cuda(), c, torch.from_numpy(eye).cuda(),
+                                                deltas=torch.from_numpy(deltas).cuda())
+    es, ec, _ = po.nerf_forward(po.model_from_module(m), x, d, enc_a, c.cpu().numpy(), eye)
+    np.testing.assert_allclose(sigma.cpu().numpy()[~dead], es[~dead], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(color.cpu().numpy()[~dead], ec[~dead], rtol=0, atol=2e-5)
+
+
+def _oracle_frame(po, scene, f, enc_a):
+    m = scene.model
+    om = po.model_from_module(m)
+    rc = po.render_cfg_from_module(m, scene.opt.dt_gamma, scene.opt.max_steps)
+    return po.render_frame(om, rc, f["rays_o"].cpu().numpy(), f["rays_d"].cpu().numpy(), enc_a.cpu().numpy(),
+                           m.individual_codes[0].detach().cpu().numpy(), f["eye"].cpu().numpy(),
+                           f["bg_coords"].cpu().numpy(), f["poses"].cpu().numpy(),
+                           m.individual_codes_torso[0].detach().cpu().numpy(), f["bg_color"].reshape(-1, 3).cpu().numpy())
+
+
+@pytest.mark.parametrize("size", [32, 64, 160])
+def test_fused_frame_matches_oracle(po, hiplib, size):
+    scene = _scene(size, "fused")
+    for i in range(3):  # iteration hint adapts after the first frame; EMA state advances
+        f = scene.frame(i)
+        with torch.no_grad():
+            out = scene.render(i)
+        enc_a = scene.model.enc_a
+        img, dep, stats = _oracle_frame(po, scene, f, enc_a)
+        got = out["image"].reshape(-1, 3).cpu().numpy()
+        st = scene.model.last_stats
+        assert st["iterations"] == stats["iterations"]
+        assert st["live_samples"] == stats["live_samples"]
+        assert np.abs(got - img).max() <= 2e-3, np.abs(got - img).max()
+        gd = out["depth"].reshape(-1).cpu().numpy()
+        assert np.array_equal(np.isnan(gd), np.isnan(dep))
+        ok = ~np.isnan(dep)
+        assert np.abs(gd[ok] - dep[ok]).max() <= 1e-3
+
+
+def test_fused_equals_ops_engine(hiplib):
+    a, b = _scene(96, "fused"), _scene(96, "ops")
+    for i in range(2):
+        with torch.no_grad():
+            ia = a.render(i)["image"]
+            ib = b.render(i)["image"]
+        assert (ia - ib).abs().max().item() <= 1e-4
+
+
+def test_opaque_regime_early_termination(po, hiplib):
+    """Regime A: sigma scaled up so rays terminate on T < T_thresh; engine and oracle agree."""
+    scene = _scene(64, "fused")
+    with torch.no_grad():
+        scene.model.sigma_net.net[-1].weight[0].abs_().mul_(40.0)
+    f = scene.frame(0)
+    with torch.no_grad():
+        out = scene.render(0)
+    img, dep, stats = _oracle_frame(po, scene, f, scene.model.enc_a)
+    st = scene.model.last_stats
+    assert abs(st["live_samples"] - stats["live_samples"]) <= 0.002 * stats["live_samples"] + 8  # knife-edge T tests
+    assert np.abs(out["image"].reshape(-1, 3).cpu().numpy() - img).max() <= 2e-3
+
+
+def test_torso_fused_matches_oracle(po, hiplib):
+    import ctypes as C
+    import radnerf_hip as hip
+    import torch.nn.functional as F
+    from radnerf import fused
+    scene = _scene(80, "fused")
+    m = scene.model
+    st = fused._state(m)
+    st.refresh()
+    N = 80 * 80
+    f = scene.frame(0)
+    bg_coords = f["bg_coords"].reshape(-1, 2).contiguous()
+    rng = np.random.default_rng(0)
+    bg_in = torch.from_numpy(rng.uniform(0, 1, (N, 3)).astype(np.float32)).cuda()
+    bg_out = torch.empty(N, 3, device="cuda")
+    alpha = torch.empty(N, device="cuda")
+    deform = torch.empty(N, 2, device="cuda")
+    thresh = min(m.density_thresh_torso, m.mean_density_torso)
+    poses = f["poses"].reshape(-1).contiguous()
+    ict = m.individual_codes_torso[0].detach().contiguous()
+    hip.call("rn_torso_fused", hip.ptr(bg_coords), N, hip.ptr(m.density_grid_torso), 128, float(thresh), hip.ptr(poses),
+             hip.ptr(ict), float(m.opt.torso_shrink), C.byref(st.tw), hip.ptr(st.tpacked), C.byref(st.gt), hip.ptr(bg_in),
+             hip.ptr(bg_out), hip.ptr(alpha), hip.ptr(deform), hip.stream())
+    occ = F.grid_sample(m.density_grid_torso.view(1, 1, 128, 128), bg_coords.view(1, -1, 1, 2), align_corners=True).view(-1)
+    mask = (occ > thresh).cpu().numpy()
+    om = po.model_from_module(m)
+    ea, ec, edx = po.torso_forward(om, bg_coords.cpu().numpy()[mask], poses.cpu().numpy(), ict.cpu().numpy())
+    ga, gd = alpha.cpu().numpy(), deform.cpu().numpy()
+    assert mask.sum() > 500
+    assert not ga[~mask].any() and not gd[~mask].any()
+    np.testing.assert_allclose(gd[mask], edx, rtol=0, atol=3e-5)
+    np.testing.assert_allclose(ga[mask], ea[:, 0], rtol=0, atol=3e-5)
+    exp_bg = bg_in.cpu().numpy().copy()
+    exp_bg[mask] = ec * ea + exp_bg[mask] * (1 - ea)
+    np.testing.assert_allclose(bg_out.cpu().numpy(), exp_bg, rtol=0, atol=5e-5)

@@ -243,7 +243,7 @@ def test_march_rays_train_bit_exact(po, hiplib, rng, N, mean_count, force):
     m = xyzs.shape[0]
     if force or mean_count <= 0:
         total = int(ecnt[0])
-        assert m == total + 128 - total % 128
+        assert m == min(M, total + 128 - total % 128)  # slicing past the buffer keeps what exists
     assert np.array_equal(n(xyzs), ex[:m]) and np.array_equal(n(dirs), ed[:m]) and np.array_equal(n(deltas), edl[:m])
     if mean_count > 0 and not force and N > 1:
         assert int(ecnt[0]) > M  # the budget really dropped rays
