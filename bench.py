@@ -50,6 +50,11 @@ def pick_engine(name):
 # Algorithmic bytes per sample: xyz grid 16 levels x 8 corners x 8 B = 1024 B gathered
 # + 12 B of coordinates in + 128 B of features out.
 GRID_XYZ_BYTES_PER_SAMPLE = 1024 + 12 + 128
+# Fused per-sample kernel (fp32 tables): 1024 B (xyz grid) + 512 B (ambient grid: 16 levels x 4 corners x 8 B)
+# gathered, + 12 B xyz + 12 B dir + 4 B delta in, + 4 B sigma + 12 B rgb out; encodings / activations stay on chip.
+FUSED_BYTES_PER_SAMPLE = 1024 + 512 + 12 + 12 + 4 + 4 + 12
+MLP_FLOP_PER_SAMPLE = 56704          # 2 x 28352 MAC
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 
 
 def kernel_select(engine, acc):
@@ -136,6 +141,9 @@ def main():
         acc = {}
         timer = hip.KernelTimer(kernel_select(engine, acc))
         hip.set_timer(timer)
+        if engine == "fused":
+            hip.prof_enable(True)
+        live0 = fpr.live_samples
         barrier()
         t0 = time.perf_counter()
         for s in range(W, W + K):
@@ -144,8 +152,14 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         hip.set_timer(None)
-        # untimed replay of a few of the timed frames to count live samples per frame
-        live_pf, slots_pf = fpr.count_samples(list(range(W, W + min(K, 8))))
+        if engine == "fused":
+            fused_launches, fused_ms = hip.prof_collect()
+            hip.prof_enable(False)
+            live_total = fpr.live_samples - live0          # from the device-side loop statistics of each frame
+            live_pf, slots_pf = live_total / K, (fpr.sample_slots) / (K + W)
+        else:
+            # untimed replay of a few of the timed frames to count live samples per frame
+            live_pf, slots_pf = fpr.count_samples(list(range(W, W + min(K, 8))))
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if dist is not None:
@@ -157,6 +171,19 @@ def main():
     if rank == 0:
         res = timer.results()
         roof = None
+        if engine == "fused" and fused_launches:
+            nbytes = live_total * FUSED_BYTES_PER_SAMPLE
+            achieved = nbytes / (fused_ms * 1e-3) / 1e9
+            tflops = live_total * MLP_FLOP_PER_SAMPLE / (fused_ms * 1e-3) / 1e12
+            roof = dict(bound="hbm", kernel="k_nerf_fused (grid gathers + fp32 MFMA MLPs)", achieved=achieved,
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=fpr.measured_traffic("nerf_fused"), launches=fused_launches,
+                        avg_launch_ms=fused_ms / fused_launches,
+                        algorithmic_bytes_per_launch=nbytes / fused_launches,
+                        algorithmic_bytes_per_sample=FUSED_BYTES_PER_SAMPLE,
+                        share_of_step=fused_ms / (elapsed * 1e3),
+                        mfma=dict(achieved_tflops=tflops, peak_tflops=MFMA_F32_PEAK_TFLOPS,
+                                  frac=tflops / MFMA_F32_PEAK_TFLOPS, flop_per_sample=MLP_FLOP_PER_SAMPLE))
         for key, r in res.items():
             per_launch_bytes = acc.get(key, 0.0) / max(r["launches"], 1)
             achieved = per_launch_bytes / (r["avg_ms"] * 1e-3) / 1e9 if r["avg_ms"] > 0 else 0.0

@@ -55,6 +55,10 @@ const char *rn_last_error(void);
 int rn_version(void);
 /* Number of visible HIP devices (>=0), or RN_ERR_NO_DEVICE. Does not create a context. */
 int rn_device_count(void);
+/* HIP-event timing of the fused per-sample kernel on its launch stream: enable(1) resets the record,
+ * collect() waits for the recorded events and returns the number of launches and their summed duration. */
+int rn_prof_enable(int on);
+int rn_prof_collect(uint32_t *launches, float *total_ms);
 
 /* ===================================================================== raymarching
  * reference: raymarching/src/raymarching.h:7-20, kernels in raymarching/src/raymarching.cu */

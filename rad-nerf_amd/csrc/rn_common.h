@@ -18,6 +18,10 @@ constexpr int kWave = 64;  // CDNA wavefront width
 
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+// HIP-event timing of the dominant kernel (rn_prof_enable / rn_prof_collect)
+bool prof_enabled();
+void prof_begin(hipStream_t s);
+void prof_end(hipStream_t s);
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(rn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

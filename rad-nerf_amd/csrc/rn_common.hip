@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <utility>
+#include <vector>
+
 namespace rn {
 
 static thread_local char g_err[512] = "";
@@ -24,9 +27,50 @@ int check_launch(const char *what) {
     return RN_OK;
 }
 
+// ---- optional HIP-event timing of one named kernel family (used by bench.py for the roofline object) ----
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static size_t g_prof_used = 0;
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_begin(hipStream_t s) {
+    if (g_prof_used == g_prof_pool.size()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        g_prof_pool.emplace_back(a, b);
+    }
+    (void)hipEventRecord(g_prof_pool[g_prof_used].first, s);
+}
+
+void prof_end(hipStream_t s) {
+    (void)hipEventRecord(g_prof_pool[g_prof_used].second, s);
+    g_prof_used++;
+}
+
 }  // namespace rn
 
 extern "C" {
+
+int rn_prof_enable(int on) {
+    rn::g_prof_on = on != 0;
+    rn::g_prof_used = 0;
+    return RN_OK;
+}
+
+int rn_prof_collect(uint32_t *launches, float *total_ms) {
+    float total = 0.0f;
+    for (size_t i = 0; i < rn::g_prof_used; i++) {
+        if (hipEventSynchronize(rn::g_prof_pool[i].second) != hipSuccess) return RN_ERR_LAUNCH;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, rn::g_prof_pool[i].first, rn::g_prof_pool[i].second) != hipSuccess) return RN_ERR_LAUNCH;
+        total += ms;
+    }
+    if (launches) *launches = (uint32_t)rn::g_prof_used;
+    if (total_ms) *total_ms = total;
+    return RN_OK;
+}
 
 const char *rn_last_error(void) { return rn::g_err; }
 

@@ -866,10 +866,13 @@ static int run_fused(const float *xyzs, const float *dirs, const float *deltas, 
                      const rn_grid_t *gx, const rn_grid_t *gw, const float *packed, const float *bias, float bound,
                      float *sigmas, float *rgbs, float *ambient, hipStream_t s) {
     FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient};
+    const bool prof = prof_enabled();
+    if (prof) prof_begin(s);
     if (gx->dtype == RN_F32 && gw->dtype == RN_F32) launch_fused<float, float>(p, s);
     else if (gx->dtype == RN_F16 && gw->dtype == RN_F16) launch_fused<__half, __half>(p, s);
     else if (gx->dtype == RN_F32) launch_fused<float, __half>(p, s);
     else launch_fused<__half, float>(p, s);
+    if (prof) prof_end(s);
     return RN_OK;
 }
 

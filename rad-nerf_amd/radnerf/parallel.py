@@ -33,6 +33,8 @@ class FrameParallelRenderer:
         self.gather = gather and dist is not None and world > 1
         self.pending = []
         self.frames_u8 = None
+        self.live_samples = 0   # summed from the engine's per-frame loop statistics when it provides them
+        self.sample_slots = 0
 
     # -- audio state ------------------------------------------------------------------------------
     def _advance_audio(self, frames):
@@ -50,6 +52,9 @@ class FrameParallelRenderer:
         self._advance_audio(skipped_frames(step, self.rank, self.world))
         g = frame_of(step, self.rank, self.world)
         out = self.scene.render(g)
+        st = self.scene.model.last_stats or {}
+        self.live_samples += st.get("live_samples", 0)
+        self.sample_slots += st.get("sample_slots", 0)
         image = out["image"]
         u8 = (image.reshape(self.scene.H, self.scene.W, 3) * 255).to(torch.uint8)
         if self.gather:

@@ -69,29 +69,37 @@ def torso_grid(grid_size=128, row_from=0.6, col_from=0.1, col_to=0.9):
     return g.reshape(-1)
 
 
+def init_synthetic_state(model, opt, seed=0, semi_axes=(0.40, 0.42, 0.40), embedding_range=0.5):
+    """Put a freshly constructed NeRFNetwork-like module (this tree's or the reference's) into the synthetic
+    scene's state: re-drawn grid tables, ellipsoid occupancy bitfield, lower-centre torso grid."""
+    # the shipped 1e-4 init gives featureless encodings; re-draw the tables (SURVEY 8(d))
+    g = torch.Generator().manual_seed(seed + 1)
+    for enc in (model.encoder, model.encoder_ambient, getattr(model, "torso_encoder", None)):
+        if enc is not None:
+            enc.embeddings.data = (torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * embedding_range
+    bits, dens = ellipsoid_bitfield(model.grid_size, float(opt.bound), semi_axes)
+    with torch.no_grad():
+        model.density_bitfield.copy_(torch.from_numpy(bits))
+        model.density_grid.copy_(torch.from_numpy(dens))
+        model.mean_density = float(dens.mean())
+        if opt.torso:
+            model.density_grid_torso.copy_(torch.from_numpy(torso_grid(model.grid_size)))
+            model.mean_density_torso = 0.29
+    return model
+
+
 class SyntheticScene:
     def __init__(self, H=512, W=512, n_frames=250, device="cuda", seed=0, opt=None, semi_axes=(0.40, 0.42, 0.40),
-                 embedding_range=0.5):
-        from .network import NeRFNetwork  # late import: needs the HIP extension to be loadable
-
+                 embedding_range=0.5, model=None):
         self.H, self.W, self.n_frames = H, W, n_frames
         self.device = torch.device(device)
         self.opt = opt if opt is not None else default_opt()
 
-        torch.manual_seed(seed)
-        model = NeRFNetwork(self.opt)
-        # the shipped 1e-4 init gives featureless encodings; re-draw the tables
-        g = torch.Generator().manual_seed(seed + 1)
-        for enc in (model.encoder, model.encoder_ambient, getattr(model, "torso_encoder", None)):
-            if enc is not None:
-                enc.embeddings.data = (torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * embedding_range
-        bits, dens = ellipsoid_bitfield(model.grid_size, float(self.opt.bound), semi_axes)
-        model.density_bitfield.copy_(torch.from_numpy(bits))
-        model.density_grid.copy_(torch.from_numpy(dens))
-        model.mean_density = float(dens.mean())
-        if self.opt.torso:
-            model.density_grid_torso.copy_(torch.from_numpy(torso_grid(model.grid_size)))
-            model.mean_density_torso = 0.29
+        if model is None:
+            from .network import NeRFNetwork  # late import: needs the HIP extension to be loadable
+            torch.manual_seed(seed)
+            model = NeRFNetwork(self.opt)
+        init_synthetic_state(model, self.opt, seed, semi_axes, embedding_range)
         self.model = model.to(self.device).eval()
 
         # pose stream: OrbitCamera, yaw 8 deg * sin(2 pi t / 4 s), pitch 4 deg * sin(2 pi t / 2.5 s), 25 FPS

@@ -70,10 +70,29 @@ _lib.rn_compact_rays_workspace.restype = _sz
 _lib.rn_compact_rays_workspace.argtypes = [_u32]
 
 
+_lib.rn_prof_enable.argtypes = [C.c_int]
+_lib.rn_prof_enable.restype = C.c_int
+_lib.rn_prof_collect.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+_lib.rn_prof_collect.restype = C.c_int
+
+
 def exported_symbols():
     """Every symbol include/radnerf_hip.h declares (used by the CPU-side load test)."""
-    return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count",
-                                       "rn_march_rays_train_workspace", "rn_compact_rays_workspace"])
+    return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count", "rn_prof_enable",
+                                       "rn_prof_collect", "rn_march_rays_train_workspace", "rn_compact_rays_workspace"])
+
+
+def prof_enable(on=True):
+    _lib.rn_prof_enable(1 if on else 0)
+
+
+def prof_collect():
+    """(launches, total_ms) of the fused per-sample kernel since prof_enable(True)."""
+    n, ms = C.c_uint32(0), C.c_float(0.0)
+    rc = _lib.rn_prof_collect(C.byref(n), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError(f"rn_prof_collect failed ({rc}): {last_error()}")
+    return int(n.value), float(ms.value)
 
 
 def last_error():
