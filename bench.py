@@ -143,7 +143,7 @@ def main():
         hip.set_timer(timer)
         if engine == "fused":
             hip.prof_enable(True)
-        live0 = fpr.live_samples
+            c0 = fpr.loop_counters() or [0, 0, 0]
         barrier()
         t0 = time.perf_counter()
         for s in range(W, W + K):
@@ -155,8 +155,9 @@ def main():
         if engine == "fused":
             fused_launches, fused_ms = hip.prof_collect()
             hip.prof_enable(False)
-            live_total = fpr.live_samples - live0          # from the device-side loop statistics of each frame
-            live_pf, slots_pf = live_total / K, (fpr.sample_slots) / (K + W)
+            c1 = fpr.loop_counters()                        # device-side loop statistics (cumulative counters)
+            live_total = (c1[1] - c0[1]) & 0xFFFFFFFF
+            live_pf, slots_pf = live_total / K, ((c1[2] - c0[2]) & 0xFFFFFFFF) / K
         else:
             # untimed replay of a few of the timed frames to count live samples per frame
             live_pf, slots_pf = fpr.count_samples(list(range(W, W + min(K, 8))))

@@ -100,10 +100,11 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream);
  * (step >= max_steps or no ray alive) are no-ops decided on the device. */
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
                     const float *bias, uint32_t first_iter, uint32_t n_iters, rn_stream_t stream);
-/* Layout of h->state after the loop (int32 words): */
+/* Layout of h->state (int32 words).  Words 0..15 are the loop state, reset by rn_head_begin; words 16.. are
+ * statistics that ACCUMULATE across frames (wrapping int32; the caller zeroes them when it wants to). */
 #define RN_HEAD_ST_ACTIVE 4      /* state[(iter & 1) * 8 + 4]: 1 while the loop wants another iteration */
 #define RN_HEAD_ST_ITERS 16      /* iterations that did work */
-#define RN_HEAD_ST_LIVE 17       /* live samples evaluated (low 32 bits), */
+#define RN_HEAD_ST_LIVE 17       /* live samples evaluated */
 #define RN_HEAD_ST_SLOTS 18      /* sample slots n_alive * n_step summed over iterations */
 
 /* ---- torso + blend ----------------------------------------------------------------------------------- */

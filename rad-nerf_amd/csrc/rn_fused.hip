@@ -398,7 +398,7 @@ k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     if (n == 0) {
         next_state(state, N, N, 0, max_steps);
-        for (int i = 8; i < RN_HEAD_STATE_INTS; i++) state[i] = 0;
+        for (int i = 8; i < 16; i++) state[i] = 0;  // statistics words [16..] accumulate across frames (caller-owned)
     }
     if (n >= N) return;
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];

@@ -5,9 +5,9 @@ Per frame the host enqueues, on torch's current stream and without reading anyth
 
     rn_nerf_frame_bias   broadcast inputs (audio code, eye, individual code) -> 3 x 64 bias values
     rn_head_begin        near/far + loop state
-    rn_head_iterate      K x {march, fused network (grid gathers + fp32 MFMA MLPs), composite, stable compaction}
+    rn_head_iterate      max_steps x {march, fused network (grid gathers + fp32 MFMA MLPs), composite, stable
+                         compaction}; iterations after the loop has ended are device-side no-ops
     rn_torso_fused       torso occupancy test + deformation / torso MLPs + blend over the background
-    (read 1 int)         "does the loop want more iterations?" -- overlapped with the torso kernel; K adapts
     rn_blend_frame       image + (1 - weights_sum) * bg, clamp, depth normalisation [, uint8]
 
 Results equal the per-operator engine's (same DDA samples, same grid features, fp32 MLPs; parity tests in
@@ -120,7 +120,6 @@ class FusedState:
                         if model.torso else None)
         self._versions = None
         self._N = 0
-        self.iters_hint = None
         self._zero_eye = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
     # -- weights --------------------------------------------------------------------------------------
@@ -177,10 +176,48 @@ class FusedState:
         self.sigmas = torch.empty(N, dtype=f32, device=d)
         self.rgbs = torch.empty(N, 3, dtype=f32, device=d)
         self.state = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32, device=d)
+        self.stats_prev = [0, 0, 0]
         self.block_counts = torch.empty((N + 255) // 256 + 1, dtype=i32, device=d)
-        self.bg = torch.empty(N, 3, dtype=f32, device=d)
-        self.state_host = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32).pin_memory()
         self._N = N
+
+
+class LoopStats(dict):
+    """Loop statistics of the frame just enqueued, read back lazily (first access synchronises the stream).
+    The device counters accumulate across frames; a frame's numbers are the difference to the previous read."""
+
+    def __init__(self, st):
+        super().__init__()
+        self._st, self._loaded = st, False
+
+    def _load(self):
+        if not self._loaded:
+            st = self._st
+            cur = st.state[ST_ITERS:ST_SLOTS + 1].cpu().tolist()
+            prev = st.stats_prev
+            st.stats_prev = cur
+            super().update(iterations=(cur[0] - prev[0]) & 0xFFFFFFFF, live_samples=(cur[1] - prev[1]) & 0xFFFFFFFF,
+                           sample_slots=(cur[2] - prev[2]) & 0xFFFFFFFF)
+            self._loaded = True
+
+    def __getitem__(self, k):
+        self._load()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._load()
+        return super().get(k, default)
+
+    def __contains__(self, k):
+        self._load()
+        return super().__contains__(k)
+
+
+def loop_counters(model):
+    """Cumulative device-side loop counters (iterations, live samples, sample slots); synchronises."""
+    st = getattr(model, "_fused_state", None)
+    if st is None or st._N == 0:
+        return None
+    return st.state[ST_ITERS:ST_SLOTS + 1].cpu().tolist()
 
 
 def _state(model):
@@ -246,14 +283,13 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     h.sigmas, h.rgbs = st.sigmas.data_ptr(), st.rgbs.data_ptr()
     h.state, h.block_counts = st.state.data_ptr(), st.block_counts.data_ptr()
 
+    # The whole <= max_steps loop is enqueued without reading anything back: iterations past the end of the loop
+    # are no-ops decided on the device (a few microseconds each), so the host can run ahead of the GPU.
     hip.call("rn_head_begin", C.byref(h), s)
-    k = min(int(max_steps), st.iters_hint + 1) if st.iters_hint else int(max_steps)
-    hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0, k, s)
-    st.state_host.copy_(st.state, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0,
+             int(max_steps), s)
 
-    # torso layer over the background (independent of the head loop: runs while the host reads the loop state)
+    # torso layer over the background
     bg_in = None
     if torch.is_tensor(bg_color):
         bg_in = bg_color.reshape(-1, 3).contiguous().float()
@@ -269,30 +305,14 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
         poses = poses.reshape(-1).contiguous().float()
         bg_coords = bg_coords.contiguous().float()
         talpha = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        bg_final = torch.empty(N, 3, dtype=torch.float32, device=dev)
         hip.call("rn_torso_fused", hip.ptr(bg_coords), N, hip.ptr(model.density_grid_torso), int(model.grid_size),
                  float(thresh), hip.ptr(poses), hip.ptr(ict), float(model.opt.torso_shrink), C.byref(st.tw),
-                 hip.ptr(st.tpacked), C.byref(st.gt), hip.ptr(bg_in), hip.ptr(st.bg), hip.ptr(talpha), None, s)
-        bg_final = st.bg
+                 hip.ptr(st.tpacked), C.byref(st.gt), hip.ptr(bg_in), hip.ptr(bg_final), hip.ptr(talpha), None, s)
         results["torso_alpha"] = talpha
-        results["torso_color"] = st.bg
+        results["torso_color"] = bg_final
 
-    # loop control: did K iterations finish the loop?  (one pinned int read, overlapped with the torso kernel)
-    ev.synchronize()
-    done = k
-    while True:
-        bank = (done & 1) * 8
-        if int(st.state_host[bank + ST_ACTIVE]) == 0 or done >= int(max_steps):
-            break
-        more = int(max_steps) - done
-        hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), done,
-                 more, s)
-        done += more
-        st.state_host.copy_(st.state, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-    iters = int(st.state_host[ST_ITERS])
-    st.iters_hint = max(iters, 1)
-    model.last_stats = {"iterations": iters, "live_samples": int(st.state_host[ST_LIVE]),
-                        "sample_slots": int(st.state_host[ST_SLOTS]), "enqueued_iterations": done}
+    model.last_stats = LoopStats(st)
 
     u8 = torch.empty(N, 3, dtype=torch.uint8, device=dev) if want_u8 else None
     hip.call("rn_blend_frame", hip.ptr(image), hip.ptr(weights_sum), hip.ptr(bg_final), hip.ptr(depth), hip.ptr(st.nears),

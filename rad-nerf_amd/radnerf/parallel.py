@@ -33,8 +33,6 @@ class FrameParallelRenderer:
         self.gather = gather and dist is not None and world > 1
         self.pending = []
         self.frames_u8 = None
-        self.live_samples = 0   # summed from the engine's per-frame loop statistics when it provides them
-        self.sample_slots = 0
 
     # -- audio state ------------------------------------------------------------------------------
     def _advance_audio(self, frames):
@@ -52,9 +50,6 @@ class FrameParallelRenderer:
         self._advance_audio(skipped_frames(step, self.rank, self.world))
         g = frame_of(step, self.rank, self.world)
         out = self.scene.render(g)
-        st = self.scene.model.last_stats or {}
-        self.live_samples += st.get("live_samples", 0)
-        self.sample_slots += st.get("sample_slots", 0)
         image = out["image"]
         u8 = (image.reshape(self.scene.H, self.scene.W, 3) * 255).to(torch.uint8)
         if self.gather:
@@ -62,19 +57,34 @@ class FrameParallelRenderer:
                 self.frames_u8 = torch.empty((self.world,) + tuple(u8.shape), dtype=torch.uint8, device=u8.device)
             # async: RCCL runs the gather on its own stream, overlapping the next frame's kernels
             buf = torch.empty_like(self.frames_u8)
-            work = self.dist.all_gather_into_tensor(buf, u8.contiguous(), async_op=True)
+            if self.dist.get_backend() == "nccl":
+                work = self.dist.all_gather_into_tensor(buf, u8.contiguous(), async_op=True)
+            else:  # gloo (CPU tests)
+                work = self.dist.all_gather(list(buf.unbind(0)), u8.contiguous(), async_op=True)
             self.pending.append((work, buf, u8))
         self.last_frame = u8
         return u8
 
     def finish(self):
+        """Wait for every outstanding gather; returns the gathered [world, H, W, 3] uint8 stacks in step order."""
+        done = []
         for work, buf, _ in self.pending:
             work.wait()
-        if self.pending:
-            self.frames_u8 = self.pending[-1][1]
+            done.append(buf)
+        if done:
+            self.frames_u8 = done[-1]
         self.pending = []
+        return done
 
     # -- bookkeeping for bench.py -------------------------------------------------------------------
+    def loop_counters(self):
+        """Cumulative (iterations, live samples, sample slots) of the fused engine's device-side loop, or None."""
+        try:
+            from . import fused
+        except ImportError:
+            return None
+        return fused.loop_counters(self.scene.model)
+
     def count_samples(self, steps):
         """Untimed replay of `steps` with the per-iteration live-sample count switched on; returns the mean
         number of live samples (deltas[:,0] > 0) and of padded sample slots per frame."""

@@ -1,0 +1,120 @@
+"""Frame-parallel sharding (radnerf/parallel.py) on CPU with the gloo backend, world_size 2 and 3: the frames
+every rank ends up with, and the lip-smoothing EMA state each rank renders with, must equal a sequential
+single-process render of the same stream.  The renderer itself is replaced by a small deterministic stand-in
+(no GPU here); what is under test is the sharding / audio-state / gather logic bench.py relies on."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+H = W = 8
+
+
+class _StandInModel:
+    """encode_audio + EMA exactly like NeRFRenderer._audio_code (nerf/renderer.py:188-194)."""
+    smooth_lips = True
+
+    def __init__(self):
+        self.enc_a = None
+        self.last_stats = None
+
+    def encode_audio(self, auds):
+        return auds.mean(dim=(0, 2)).reshape(1, -1) * 0.1
+
+
+class _StandInScene:
+    def __init__(self, n_frames):
+        from types import SimpleNamespace
+        self.H, self.W, self.n_frames = H, W, n_frames
+        self.opt = SimpleNamespace(att=2)
+        g = torch.Generator().manual_seed(0)
+        self.aud_features = torch.randn(n_frames, 6, 16, generator=g)
+        self.model = _StandInModel()
+        self.log = []
+
+    def render(self, i):
+        from radnerf.rays import get_audio_features
+        m = self.model
+        enc = m.encode_audio(get_audio_features(self.aud_features, 2, i % self.n_frames))
+        if m.enc_a is not None:
+            enc = 0.35 * m.enc_a + (1 - 0.35) * enc
+        m.enc_a = enc
+        self.log.append((i, enc.clone()))
+        base = torch.sigmoid(enc.sum()) * 0.5 + (i % 7) / 20.0
+        img = (base + torch.arange(H * W * 3, dtype=torch.float32).reshape(1, H * W, 3) / (H * W * 3) * 0.3).clamp(0, 1)
+        return {"image": img}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sequential(n_total, n_frames):
+    scene = _StandInScene(n_frames)
+    frames, encs = [], []
+    for g in range(n_total):
+        out = scene.render(g)
+        frames.append((out["image"].reshape(H, W, 3) * 255).to(torch.uint8))
+        encs.append(scene.model.enc_a.clone())
+    return frames, encs
+
+
+def _worker(rank, world, port, steps, n_frames, ret):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from radnerf.parallel import FrameParallelRenderer, frame_of
+    scene = _StandInScene(n_frames)
+    fpr = FrameParallelRenderer(scene, rank, world, dist)
+    for s in range(steps):
+        fpr.step(s)
+    stacks = fpr.finish()
+    ret[rank] = dict(stacks=[t.numpy() for t in stacks],
+                     encs={frame_of(s, rank, world): None for s in range(steps)},
+                     log=[(i, e.numpy()) for i, e in scene.log])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_parallel_equals_sequential(hiplib, world):
+    steps, n_frames = 4, 16
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, steps, n_frames, ret), nprocs=world, join=True)
+    seq_frames, seq_encs = _sequential(steps * world, n_frames)
+    for rank in range(world):
+        r = ret[rank]
+        assert len(r["stacks"]) == steps
+        for s in range(steps):
+            stack = r["stacks"][s]  # [world, H, W, 3]: frame s*world + q rendered by rank q
+            for q in range(world):
+                assert np.array_equal(stack[q], seq_frames[s * world + q].numpy()), (rank, s, q)
+        # the EMA state this rank rendered with equals the sequential one at its global frames
+        rendered = {i: e for i, e in r["log"]}
+        for s in range(steps):
+            g = s * world + rank
+            np.testing.assert_allclose(rendered[g], seq_encs[g].numpy(), rtol=0, atol=1e-7)
+
+
+def test_skipped_frames_partition():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
+    from radnerf.parallel import frame_of, skipped_frames
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            seen = []
+            for s in range(5):
+                seen += skipped_frames(s, rank, world) + [frame_of(s, rank, world)]
+            assert seen == list(range(frame_of(4, rank, world) + 1))  # every frame's audio is folded exactly once, in order
