@@ -154,9 +154,11 @@ def main():
         hip.set_timer(None)
         if engine == "fused":
             fused_launches, fused_ms = hip.prof_collect()
+            fused_durs = sorted(hip.prof_durations(), reverse=True)
             hip.prof_enable(False)
             c1 = fpr.loop_counters()                        # device-side loop statistics (cumulative counters)
             live_total = (c1[1] - c0[1]) & 0xFFFFFFFF
+            iters_total = (c1[0] - c0[0]) & 0xFFFFFFFF      # launches that had samples to process
             live_pf, slots_pf = live_total / K, ((c1[2] - c0[2]) & 0xFFFFFFFF) / K
         else:
             # untimed replay of a few of the timed frames to count live samples per frame
@@ -183,6 +185,10 @@ def main():
                         algorithmic_bytes_per_launch=nbytes / fused_launches,
                         algorithmic_bytes_per_sample=FUSED_BYTES_PER_SAMPLE,
                         share_of_step=fused_ms / (elapsed * 1e3),
+                        launches_with_work=iters_total,
+                        avg_launch_ms_with_work=sum(fused_durs[:iters_total]) / max(iters_total, 1),
+                        note="launches/avg_launch_ms count every launch of the kernel (max_steps per frame, as rocprof "
+                             "does); iterations past the end of the loop launch with zero samples and exit at once",
                         mfma=dict(achieved_tflops=tflops, peak_tflops=MFMA_F32_PEAK_TFLOPS,
                                   frac=tflops / MFMA_F32_PEAK_TFLOPS, flop_per_sample=MLP_FLOP_PER_SAMPLE))
         for key, r in res.items():

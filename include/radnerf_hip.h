@@ -59,6 +59,8 @@ int rn_device_count(void);
  * collect() waits for the recorded events and returns the number of launches and their summed duration. */
 int rn_prof_enable(int on);
 int rn_prof_collect(uint32_t *launches, float *total_ms);
+/* Per-launch durations (ms) in launch order; returns how many were written (<= capacity) or a negative error. */
+int rn_prof_durations(float *out_ms, uint32_t capacity);
 
 /* ===================================================================== raymarching
  * reference: raymarching/src/raymarching.h:7-20, kernels in raymarching/src/raymarching.cu */

@@ -72,6 +72,15 @@ int rn_prof_collect(uint32_t *launches, float *total_ms) {
     return RN_OK;
 }
 
+int rn_prof_durations(float *out_ms, uint32_t capacity) {
+    const size_t n = rn::g_prof_used < capacity ? rn::g_prof_used : capacity;
+    for (size_t i = 0; i < n; i++) {
+        if (hipEventSynchronize(rn::g_prof_pool[i].second) != hipSuccess) return RN_ERR_LAUNCH;
+        if (hipEventElapsedTime(&out_ms[i], rn::g_prof_pool[i].first, rn::g_prof_pool[i].second) != hipSuccess) return RN_ERR_LAUNCH;
+    }
+    return (int)n;
+}
+
 const char *rn_last_error(void) { return rn::g_err; }
 
 int rn_version(void) { return 100; }  // 0.1.0

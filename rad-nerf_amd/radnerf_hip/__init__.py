@@ -76,10 +76,14 @@ _lib.rn_prof_collect.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
 _lib.rn_prof_collect.restype = C.c_int
 
 
+_lib.rn_prof_durations.argtypes = [C.POINTER(C.c_float), C.c_uint32]
+_lib.rn_prof_durations.restype = C.c_int
+
+
 def exported_symbols():
     """Every symbol include/radnerf_hip.h declares (used by the CPU-side load test)."""
     return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count", "rn_prof_enable",
-                                       "rn_prof_collect", "rn_march_rays_train_workspace", "rn_compact_rays_workspace"])
+                                       "rn_prof_collect", "rn_prof_durations", "rn_march_rays_train_workspace", "rn_compact_rays_workspace"])
 
 
 def prof_enable(on=True):
@@ -152,6 +156,15 @@ def call(name, *args):
     rc = getattr(_lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
+
+
+def prof_durations(capacity=1 << 16):
+    """Per-launch durations (ms) of the fused per-sample kernel since prof_enable(True)."""
+    buf = (C.c_float * capacity)()
+    n = _lib.rn_prof_durations(buf, capacity)
+    if n < 0:
+        raise RuntimeError(f"rn_prof_durations failed ({n}): {last_error()}")
+    return [float(buf[i]) for i in range(n)]
 
 
 def workspace_bytes(name, n):
