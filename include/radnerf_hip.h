@@ -50,6 +50,9 @@ typedef void *rn_stream_t; /* hipStream_t */
  * permute(1,0,2).reshape copy of gridencoder/grid.py:57 and :75. */
 #define RN_LAYOUT_LBC 0
 #define RN_LAYOUT_BLC 1
+/* Same memory layout as RN_LAYOUT_BLC; forward computed level-major (one (sample, level) per lane, only one
+ * level's table live in an XCD's L2 at a time) instead of one sample per lane walking all levels. */
+#define RN_LAYOUT_BLC_LEVELMAJOR 2
 
 const char *rn_last_error(void);
 int rn_version(void);

@@ -272,6 +272,9 @@ static void launch_fwd(const FwdArgs &a) {
     if (a.layout == RN_LAYOUT_LBC) {
         const dim3 grid(div_up(a.B, 256), a.L);
         if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_LBC); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_LBC);
+    } else if (a.layout == RN_LAYOUT_BLC_LEVELMAJOR) {
+        const dim3 grid(div_up(a.B, 256), a.L);
+        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_BLC); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_BLC);
     } else {
         const dim3 grid(div_up(a.B, 256));
         if (dy) RN_FWD(k_grid_fwd_sample, grid, true, RN_LAYOUT_BLC); else RN_FWD(k_grid_fwd_sample, grid, false, RN_LAYOUT_BLC);
@@ -382,7 +385,8 @@ int rn_grid_encode_forward(const float *inputs, const void *embeddings, const in
     RN_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
     RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L=%u out of range (1..%u)", L, kMaxLevels);
     RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_forward: dtype must be RN_F32 or RN_F16");
-    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_forward: bad layout");
+    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC || layout == RN_LAYOUT_BLC_LEVELMAJOR,
+               "grid_encode_forward: bad layout");
     RN_REQUIRE(gridtype <= 1 && interp <= 1, "grid_encode_forward: bad gridtype / interpolation id");
     FwdArgs a{inputs, embeddings, offsets, outputs, B, L, make_level_consts(L, S, H), dy_dx, gridtype,
               align_corners != 0, interp, layout, as_stream(stream)};
@@ -400,7 +404,9 @@ int rn_grid_encode_backward(const void *grad, const float *inputs, const void *e
     RN_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L=%u out of range (1..%u)", L, kMaxLevels);
     RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_backward: dtype must be RN_F32 or RN_F16");
-    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_backward: bad layout");
+    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC || layout == RN_LAYOUT_BLC_LEVELMAJOR,
+               "grid_encode_backward: bad layout");
+    if (layout == RN_LAYOUT_BLC_LEVELMAJOR) layout = RN_LAYOUT_BLC;
     RN_REQUIRE(gridtype <= 1 && interp <= 1, "grid_encode_backward: bad gridtype / interpolation id");
     BwdArgs a{grad, inputs, offsets, grad_embeddings, B, L, make_level_consts(L, S, H), dy_dx, grad_inputs, gridtype,
               align_corners != 0, interp, layout, as_stream(stream)};

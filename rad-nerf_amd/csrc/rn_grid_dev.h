@@ -61,6 +61,27 @@ __device__ __forceinline__ void store_row(T *p, const T (&v)[C]) {
     }
 }
 
+// Two adjacent rows with one load of 2*C scalars; the address is only guaranteed to be row-aligned
+// (C * sizeof(T)), which global loads on gfx950 accept (dword alignment is all the hardware needs).
+template <typename T, uint32_t C>
+__device__ __forceinline__ void load_pair(const T *p, T (&a)[C], T (&b)[C]) {
+    constexpr uint32_t bytes = sizeof(T) * C * 2;
+    constexpr uint32_t words = bytes / 4;
+    if constexpr (bytes == 4) {  // two fp16 scalars
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+        *reinterpret_cast<uint16_t *>(a) = (uint16_t)(w & 0xffffu);
+        *reinterpret_cast<uint16_t *>(b) = (uint16_t)(w >> 16);
+    } else {
+        typedef uint32_t vec_t __attribute__((ext_vector_type(words), aligned(4)));
+        const vec_t v = *reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+        for (uint32_t i = 0; i < words / 2; i++) {
+            reinterpret_cast<uint32_t *>(a)[i] = v[i];
+            reinterpret_cast<uint32_t *>(b)[i] = v[words / 2 + i];
+        }
+    }
+}
+
 // gridencoder.cu:50-63
 template <uint32_t D>
 __device__ __forceinline__ uint32_t fast_hash(const uint32_t (&pos_grid)[D]) {
@@ -125,15 +146,42 @@ __device__ __forceinline__ void encode_level(const T *__restrict__ grid, const f
     uint32_t pos_grid[D];
     lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
 
-    // issue all 2^D row loads first, then blend
+    // Issue all 2^D row loads first, then blend.  On levels that are not hashed, the two corners that differ
+    // only in x sit in adjacent rows (index and index + 1, unless the modulo wraps), so one load of 2*C scalars
+    // fetches both: half the load instructions and half the cache-line requests of the gather.
+    uint32_t stride_all = 1;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++)
+        if (stride_all <= hashmap_size) stride_all *= align_corners ? resolution : (resolution + 1);
+    const bool hashed = gridtype == 0 && stride_all > hashmap_size;  // wave-uniform
+    constexpr bool kCanPair = sizeof(T) * C * 2 <= 32;
+
     T rows[1 << D][C];
+    if (kCanPair && !hashed) {
 #pragma unroll
-    for (uint32_t idx = 0; idx < (1u << D); idx++) {
-        uint32_t pgl[D];
+        for (uint32_t idx = 0; idx < (1u << D); idx += 2) {
+            uint32_t pgl[D];
 #pragma unroll
-        for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
-        const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-        load_row<T, C>(grid + (size_t)row * C, rows[idx]);
+            for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
+            const uint32_t row0 = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            pgl[0] += 1;
+            const uint32_t row1 = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            if (row1 == row0 + 1) {
+                load_pair<T, C>(grid + (size_t)row0 * C, rows[idx], rows[idx + 1]);
+            } else {
+                load_row<T, C>(grid + (size_t)row0 * C, rows[idx]);
+                load_row<T, C>(grid + (size_t)row1 * C, rows[idx + 1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            uint32_t pgl[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
+            const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            load_row<T, C>(grid + (size_t)row * C, rows[idx]);
+        }
     }
 #pragma unroll
     for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);

@@ -55,7 +55,7 @@ _SIGNATURES = {
 }
 
 RN_F32, RN_F16 = 0, 1
-RN_LAYOUT_LBC, RN_LAYOUT_BLC = 0, 1
+RN_LAYOUT_LBC, RN_LAYOUT_BLC, RN_LAYOUT_BLC_LEVELMAJOR = 0, 1, 2
 
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(_lib, _name)

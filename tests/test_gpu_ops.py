@@ -322,7 +322,7 @@ GRID_CASES = [
 
 
 @pytest.mark.parametrize("D,C,L,log2T,gridtype,B", GRID_CASES)
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("interp", [0, 1])
 def test_grid_forward_fp32_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, B, layout, interp):
     import radnerf_hip as hip

@@ -75,7 +75,8 @@ def main():
                    "uniform": torch.rand(B, D, device=dev)}
             for pname, x in pts.items():
                 for dt_name, emb, dtype_id, esz in (("f32", emb32, hip.RN_F32, 4), ("f16", emb16, hip.RN_F16, 2)):
-                    for layout, lname in ((hip.RN_LAYOUT_LBC, "level-major [L,B,C]"), (hip.RN_LAYOUT_BLC, "sample-major [B,L*C]")):
+                    for layout, lname in ((hip.RN_LAYOUT_LBC, "level-major [L,B,C]"), (hip.RN_LAYOUT_BLC, "sample-major [B,L*C]"),
+                                          (hip.RN_LAYOUT_BLC_LEVELMAJOR, "level-major [B,L*C]")):
                         out = torch.empty(L * B * C, device=dev, dtype=emb.dtype)
 
                         def run():
