@@ -281,13 +281,36 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                     on = on && !(in[d] < 0 || in[d] > 1);
                 }
             }
-#pragma unroll 2
-            for (int l = 0; l < 16; l++) {
-                float f0, f1, b0, b1;
-                level_features<TX, 3>(p.gx.table, lvl_x[l], p.gx.gridtype, in, on, f0, f1);
+            // software pipeline: the row loads of level l+1 are in flight while level l is blended and fed to
+            // the matrix cores (two static fetch buffers, loop unrolled by two)
+            LevelFetch<TX, 3, 2> fa, fb;
+            auto issue = [&](int l, LevelFetch<TX, 3, 2> &f) {
+                if (on) {
+                    const LevelLds lv = lvl_x[l];
+                    issue_level<TX, 3, 2>(static_cast<const TX *>(p.gx.table) + (size_t)lv.offset * 2, in, lv.scale,
+                                          lv.resolution, lv.rows, p.gx.gridtype, false, 0, f);
+                }
+            };
+            auto consume = [&](int l, const LevelFetch<TX, 3, 2> &f) {
+                float f0 = 0.0f, f1 = 0.0f, b0, b1;
+                if (on) {
+                    TX res[2];
+                    TX dummy[1];
+                    blend_level<TX, 3, 2, false>(f, lvl_x[l].scale, res, dummy);
+                    f0 = to_f<TX>(res[0]);
+                    f1 = to_f<TX>(res[1]);
+                }
                 to_b_operands(f0, f1, b0, b1);
                 step64(a0, lds + OFF_A0, l, lane_off, b0, b1);
                 step64(a2, lds + OFF_S0, l, lane_off, b0, b1);
+            };
+            issue(0, fa);
+#pragma unroll 1
+            for (int l = 0; l < 16; l += 2) {
+                issue(l + 1, fb);
+                consume(l, fa);
+                if (l + 2 < 16) issue(l + 2, fa);
+                consume(l + 1, fb);
             }
         }
 
@@ -312,12 +335,33 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
         {
             float in[2] = {(amb[0] + 1.0f) / 2.0f, (amb[1] + 1.0f) / 2.0f};
             const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
-#pragma unroll 2
-            for (int l = 0; l < 16; l++) {
-                float f0, f1, b0, b1;
-                level_features<TW, 2>(p.gw.table, lvl_w[l], p.gw.gridtype, in, on, f0, f1);
+            LevelFetch<TW, 2, 2> fa, fb;
+            auto issue = [&](int l, LevelFetch<TW, 2, 2> &f) {
+                if (on) {
+                    const LevelLds lv = lvl_w[l];
+                    issue_level<TW, 2, 2>(static_cast<const TW *>(p.gw.table) + (size_t)lv.offset * 2, in, lv.scale,
+                                          lv.resolution, lv.rows, p.gw.gridtype, false, 0, f);
+                }
+            };
+            auto consume = [&](int l, const LevelFetch<TW, 2, 2> &f) {
+                float f0 = 0.0f, f1 = 0.0f, b0, b1;
+                if (on) {
+                    TW res[2];
+                    TW dummy[1];
+                    blend_level<TW, 2, 2, false>(f, lvl_w[l].scale, res, dummy);
+                    f0 = to_f<TW>(res[0]);
+                    f1 = to_f<TW>(res[1]);
+                }
                 to_b_operands(f0, f1, b0, b1);
                 step64(a2, lds + OFF_S0, 16 + l, lane_off, b0, b1);
+            };
+            issue(0, fa);
+#pragma unroll 1
+            for (int l = 0; l < 16; l += 2) {
+                issue(l + 1, fb);
+                consume(l, fa);
+                if (l + 2 < 16) issue(l + 2, fa);
+                consume(l + 1, fb);
             }
         }
 

@@ -92,6 +92,14 @@ __device__ __forceinline__ uint32_t fast_hash(const uint32_t (&pos_grid)[D]) {
     return result;
 }
 
+__device__ __forceinline__ uint32_t fast_mod(uint32_t index, uint32_t hashmap_size) {
+    // index % hashmap_size without the integer division on the two cases that occur in practice:
+    // capped levels have a power-of-two row count, dense levels have index < row count.
+    if ((hashmap_size & (hashmap_size - 1u)) == 0u) return index & (hashmap_size - 1u);
+    if (index < hashmap_size) return index;
+    return index % hashmap_size;
+}
+
 // Row index of a lattice corner (gridencoder.cu:66-84 without the "* C + ch").
 template <uint32_t D>
 __device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
@@ -105,11 +113,7 @@ __device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, bool align_corne
         }
     }
     if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
-    // index % hashmap_size without the ~30-instruction integer division on the two cases that occur in
-    // practice: capped levels have a power-of-two row count, dense levels have index < row count.
-    if ((hashmap_size & (hashmap_size - 1u)) == 0u) return index & (hashmap_size - 1u);
-    if (index < hashmap_size) return index;
-    return index % hashmap_size;
+    return fast_mod(index, hashmap_size);
 }
 
 __device__ __forceinline__ float smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
@@ -134,55 +138,83 @@ __device__ __forceinline__ void lattice_pos(const float (&in)[D], float scale, b
     }
 }
 
-// Interpolated features (and optionally d/dx) of one sample at one level.
-// `grid` already points at the level's first row.  Accumulation follows the reference's
-// scalar_t semantics: results live in T and every += rounds to T (gridencoder.cu:163,186,234).
-template <typename T, uint32_t D, uint32_t C, bool DYDX>
-__device__ __forceinline__ void encode_level(const T *__restrict__ grid, const float (&in)[D], float scale,
-                                             uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
-                                             bool align_corners, uint32_t interp, T (&results)[C],
-                                             T (&grads)[DYDX ? D * C : 1]) {
-    float pos[D], pos_deriv[D];
-    uint32_t pos_grid[D];
-    lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
-
-    // Issue all 2^D row loads first, then blend.  On levels that are not hashed, the two corners that differ
-    // only in x sit in adjacent rows (index and index + 1, unless the modulo wraps), so one load of 2*C scalars
-    // fetches both: half the load instructions and half the cache-line requests of the gather.
-    uint32_t stride_all = 1;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++)
-        if (stride_all <= hashmap_size) stride_all *= align_corners ? resolution : (resolution + 1);
-    const bool hashed = gridtype == 0 && stride_all > hashmap_size;  // wave-uniform
-    constexpr bool kCanPair = sizeof(T) * C * 2 <= 32;
-
+// One level's gather in flight: the 2^D corner rows plus the interpolation fractions that will blend them.
+// Splitting "issue" from "blend" lets a caller overlap the loads of level l+1 with the arithmetic of level l.
+template <typename T, uint32_t D, uint32_t C>
+struct LevelFetch {
     T rows[1 << D][C];
-    if (kCanPair && !hashed) {
+    float pos[D], pos_deriv[D];
+};
+
+
+// Compute the lattice position and the 2^D row indices of one sample at one level and ISSUE the row loads.
+// Index arithmetic (gridencoder.cu:66-84) is hoisted per dimension: (p + 1) * m == p * m + m (mod 2^32), so a
+// level costs D multiplies instead of D * 2^D.  On levels that are not hashed the two corners that differ only
+// in x sit in adjacent rows (unless the modulo wraps): one load of 2*C scalars fetches both.
+template <typename T, uint32_t D, uint32_t C>
+__device__ __forceinline__ void issue_level(const T *__restrict__ grid, const float (&in)[D], float scale,
+                                            uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
+                                            bool align_corners, uint32_t interp, LevelFetch<T, D, C> &f) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t pos_grid[D];
+    lattice_pos<D>(in, scale, align_corners, interp, f.pos, f.pos_deriv, pos_grid);
+
+    // wave-uniform: which dimensions take part in the dense index, and is the level hashed
+    uint32_t mult[D];
+    uint32_t stride = 1;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const bool act = stride <= hashmap_size;
+        mult[d] = act ? stride : 0u;
+        if (act) stride *= align_corners ? resolution : (resolution + 1);
+    }
+    const bool hashed = gridtype == 0 && stride > hashmap_size;
+    if (hashed) {
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) mult[d] = primes[d];
+    }
+    uint32_t t0[D], t1[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        t0[d] = pos_grid[d] * mult[d];
+        t1[d] = t0[d] + mult[d];
+    }
+
+    constexpr bool kCanPair = sizeof(T) * C * 2 <= 32;
+    if (!hashed) {
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx += 2) {
-            uint32_t pgl[D];
+            uint32_t base = 0;
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
-            const uint32_t row0 = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-            pgl[0] += 1;
-            const uint32_t row1 = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-            if (row1 == row0 + 1) {
-                load_pair<T, C>(grid + (size_t)row0 * C, rows[idx], rows[idx + 1]);
+            for (uint32_t d = 1; d < D; d++) base += ((idx >> d) & 1u) ? t1[d] : t0[d];
+            const uint32_t row0 = fast_mod(base + t0[0], hashmap_size);
+            const uint32_t row1 = fast_mod(base + t1[0], hashmap_size);
+            if (kCanPair && row1 == row0 + 1) {
+                load_pair<T, C>(grid + (size_t)row0 * C, f.rows[idx], f.rows[idx + 1]);
             } else {
-                load_row<T, C>(grid + (size_t)row0 * C, rows[idx]);
-                load_row<T, C>(grid + (size_t)row1 * C, rows[idx + 1]);
+                load_row<T, C>(grid + (size_t)row0 * C, f.rows[idx]);
+                load_row<T, C>(grid + (size_t)row1 * C, f.rows[idx + 1]);
             }
         }
     } else {
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
-            uint32_t pgl[D];
+            uint32_t h = 0;
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
-            const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-            load_row<T, C>(grid + (size_t)row * C, rows[idx]);
+            for (uint32_t d = 0; d < D; d++) h ^= ((idx >> d) & 1u) ? t1[d] : t0[d];
+            load_row<T, C>(grid + (size_t)fast_mod(h, hashmap_size) * C, f.rows[idx]);
         }
     }
+}
+
+// Interpolated features (and optionally d/dx) from a completed LevelFetch.  Accumulation follows the
+// reference's scalar_t semantics: results live in T and every += rounds to T (gridencoder.cu:163,186,234).
+template <typename T, uint32_t D, uint32_t C, bool DYDX>
+__device__ __forceinline__ void blend_level(const LevelFetch<T, D, C> &f, float scale, T (&results)[C],
+                                            T (&grads)[DYDX ? D * C : 1]) {
+    const float (&pos)[D] = f.pos;
+    const float (&pos_deriv)[D] = f.pos_deriv;
+    const T (&rows)[1 << D][C] = f.rows;
 #pragma unroll
     for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);
 #pragma unroll
@@ -223,6 +255,17 @@ __device__ __forceinline__ void encode_level(const T *__restrict__ grid, const f
             for (uint32_t ch = 0; ch < C; ch++) grads[gd * C + ch] = rg[ch];
         }
     }
+}
+
+// issue + blend back to back (callers that do not pipeline)
+template <typename T, uint32_t D, uint32_t C, bool DYDX>
+__device__ __forceinline__ void encode_level(const T *__restrict__ grid, const float (&in)[D], float scale,
+                                             uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
+                                             bool align_corners, uint32_t interp, T (&results)[C],
+                                             T (&grads)[DYDX ? D * C : 1]) {
+    LevelFetch<T, D, C> f;
+    issue_level<T, D, C>(grid, in, scale, resolution, hashmap_size, gridtype, align_corners, interp, f);
+    blend_level<T, D, C, DYDX>(f, scale, results, grads);
 }
 
 }  // namespace rn

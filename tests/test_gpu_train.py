@@ -1,0 +1,153 @@
+"""GPU parity of the training-side rows of SURVEY 8(a): the train branch of run_cuda (a2: march_rays_train ->
+network -> composite_rays_train, forward and backward) and the occupancy-grid maintenance (a3: update_extra_state,
+mark_untrained_grid) of this tree's renderer mirror over the HIP operators."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(size=64, **kw):
+    from radnerf.scene import SyntheticScene, default_opt
+    return SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine="ops", **kw))
+
+
+def test_train_branch_forward_matches_oracle(po, hiplib):
+    scene = _scene(64)
+    m = scene.model
+    m.train()
+    f = scene.frame(0)
+    torch.manual_seed(0)
+    n_rays = 4096
+    idx = torch.randperm(64 * 64, device="cuda")[:n_rays]
+    rays_o, rays_d = f["rays_o"][:, idx], f["rays_d"][:, idx]
+    bg_coords = f["bg_coords"][:, idx]
+    out = m.render(rays_o, rays_d, f["auds"], bg_coords, f["poses"], eye=f["eye"], index=[3], bg_color=f["bg_color"][:, idx],
+                   perturb=False, force_all_rays=False, dt_gamma=scene.opt.dt_gamma, max_steps=scene.opt.max_steps)
+    # oracle: the same three stages (raymarching.cu:352-698 + network.py:222-283)
+    o, d = rays_o.reshape(-1, 3).cpu().numpy(), rays_d.reshape(-1, 3).cpu().numpy()
+    nears, fars = po.near_far_from_aabb(o, d, m.aabb_train.cpu().numpy(), m.min_near)
+    bits = m.density_bitfield.cpu().numpy()
+    M = n_rays * scene.opt.max_steps
+    xyzs, dirs, deltas, rays, cnt = po.march_rays_train(o, d, bits, 1.0, scene.opt.dt_gamma, scene.opt.max_steps, 1, 128, M,
+                                                        nears, fars, np.zeros(n_rays, np.float32))
+    assert int(m.step_counter[0, 0].item()) == int(cnt[0]) and int(m.step_counter[0, 1].item()) == n_rays
+    total = int(cnt[0])
+    om = po.model_from_module(m)
+    ind = m.individual_codes[3].detach().cpu().numpy()
+    sig, rgb, amb = po.nerf_forward(om, xyzs[:total], dirs[:total], m.enc_a.detach().cpu().numpy(), ind, f["eye"].cpu().numpy())
+    ws, am, dp, im = po.composite_rays_train_forward(sig, rgb, np.abs(amb).sum(-1), deltas[:total], rays, 1e-4)
+    np.testing.assert_allclose(out["weights_sum"].detach().cpu().numpy(), ws, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["ambient"].detach().cpu().numpy(), am, rtol=1e-4, atol=1e-4)
+    # the train branch also blends the torso layer and clamps (renderer.py:269-308): check the head part via weights_sum
+    # and the full image against the oracle's blend of its own pieces
+    thresh = min(m.density_thresh_torso, m.mean_density_torso)
+    import torch.nn.functional as F
+    occ = F.grid_sample(m.density_grid_torso.view(1, 1, 128, 128), bg_coords.view(1, -1, 1, 2), align_corners=True).view(-1)
+    mask = (occ > thresh).cpu().numpy()
+    bg = f["bg_color"][:, idx].reshape(-1, 3).cpu().numpy().copy()
+    if mask.any():
+        ta, tc, _ = po.torso_forward(om, bg_coords.reshape(-1, 2).cpu().numpy()[mask], f["poses"].cpu().numpy(),
+                                     m.individual_codes_torso[3].detach().cpu().numpy())
+        bg[mask] = tc * ta + bg[mask] * (1 - ta)
+    expect = np.clip(im + (1 - ws)[:, None] * bg, 0, 1)
+    np.testing.assert_allclose(out["image"].detach().reshape(-1, 3).cpu().numpy(), expect, rtol=0, atol=5e-5)
+
+
+def test_train_step_backward_is_the_gradient_of_the_loss(hiplib):
+    """Directional finite differences through the whole chain: composite_rays_train backward -> torch MLP backward ->
+    grid_encode backward (atomics) / input backward for the ambient grid."""
+    scene = _scene(48, torso=False)
+    m = scene.model
+    m.train()
+    f = scene.frame(0)
+    torch.manual_seed(1)
+    idx = torch.randperm(48 * 48, device="cuda")[:1024]
+    args = dict(eye=f["eye"], index=[0], bg_color=f["bg_color"][:, idx], perturb=False, force_all_rays=True,
+                dt_gamma=scene.opt.dt_gamma, max_steps=scene.opt.max_steps)
+    w = torch.randn(1024, 3, device="cuda")
+
+    def loss_fn():
+        m.enc_a = None
+        out = m.render(f["rays_o"][:, idx], f["rays_d"][:, idx], f["auds"], f["bg_coords"][:, idx], f["poses"], **args)
+        return (out["image"].reshape(-1, 3) * w).sum() + 0.1 * out["ambient"].sum() + 0.3 * out["weights_sum"].sum()
+
+    for p in m.parameters():
+        p.grad = None
+    loss = loss_fn()
+    loss.backward()
+    checks = {"encoder.embeddings": m.encoder.embeddings, "encoder_ambient.embeddings": m.encoder_ambient.embeddings,
+              "sigma_net.net.0.weight": m.sigma_net.net[0].weight, "ambient_net.net.2.weight": m.ambient_net.net[2].weight}
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for name, p in checks.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        v = torch.randn(p.shape, device="cuda", generator=g) * (p.grad != 0)  # direction inside the touched entries
+        v = v / (v.norm() + 1e-12)
+        analytic = float((p.grad * v).sum())
+        eps = 2e-2 if "embeddings" in name else 5e-3
+        with torch.no_grad():
+            p.add_(eps * v)
+            lp = float(loss_fn())
+            p.sub_(2 * eps * v)
+            lm = float(loss_fn())
+            p.add_(eps * v)
+        numeric = (lp - lm) / (2 * eps)
+        assert abs(numeric - analytic) <= 0.08 * max(abs(numeric), abs(analytic)) + 2e-3, (name, numeric, analytic)
+
+
+def test_update_extra_state_head(po, hiplib, monkeypatch):
+    """a3: morton coords -> density query -> morton dilation -> EMA max -> packbits, with the jitter pinned to zero."""
+    scene = _scene(16, torso=False)
+    m = scene.model
+    m.aud_features = scene.aud_features
+    m.eye_area = torch.full((scene.n_frames, 1), 0.25, device="cuda")
+    monkeypatch.setattr(torch, "rand_like", lambda x, **k: torch.full_like(x, 0.5))   # (rand*2-1) = 0
+    import random
+    monkeypatch.setattr(random, "randint", lambda a, b: 2)
+    m.density_grid.zero_()
+    m.local_step = 3
+    m.step_counter.zero_()
+    m.step_counter[:3, 0] = torch.tensor([100, 200, 330], dtype=torch.int32)
+    with torch.no_grad():
+        m.update_extra_state()
+    assert m.mean_count == 210 and m.local_step == 0
+    # oracle recomputation
+    H = 128
+    ii = np.arange(H, dtype=np.int32)
+    coords = np.stack(np.meshgrid(ii, ii, ii, indexing="ij"), -1).reshape(-1, 3)
+    mort = po.morton3D(coords)
+    xyz = ((2 * coords.astype(np.float32) / (H - 1) - 1) * np.float32(1 - 1 / H)).astype(np.float32)
+    from radnerf.rays import get_audio_features
+    with torch.no_grad():
+        enc_a = m.encode_audio(get_audio_features(scene.aud_features, 2, 2)).cpu().numpy()
+    sig = po.nerf_density(po.model_from_module(m), xyz, enc_a, np.array([[0.25]], np.float32))
+    tmp = np.zeros((1, H ** 3), np.float32)
+    tmp[0, mort] = sig
+    dil = po.morton3D_dilation(tmp)
+    got = m.density_grid.cpu().numpy()
+    np.testing.assert_allclose(got, np.maximum(0 * 0.95, dil), rtol=2e-3, atol=1e-5)
+    assert abs(m.mean_density - float(np.clip(got, 0, None).mean())) < 1e-5
+    assert np.array_equal(m.density_bitfield.cpu().numpy(), po.packbits(got, min(m.mean_density, m.density_thresh)))
+
+
+def test_update_extra_state_torso_and_mark_untrained(hiplib, monkeypatch):
+    scene = _scene(16)
+    m = scene.model
+    m.aud_features = scene.aud_features
+    m.poses = scene.poses
+    m.eye_area = torch.full((scene.n_frames, 1), 0.25, device="cuda")
+    before = m.density_grid_torso.clone()
+    with torch.no_grad():
+        m.update_extra_state()
+    assert m.density_grid_torso.shape == before.shape and torch.isfinite(m.density_grid_torso).all()
+    assert (m.density_grid_torso >= before * 0.95 - 1e-6).all()          # EMA max never drops below the decayed value
+    assert abs(m.mean_density_torso - float(m.density_grid_torso.mean())) < 1e-6
+    # mark_untrained_grid: cells outside every training frustum become -1 (renderer.py:318-379)
+    m.density_grid.zero_()
+    m.mark_untrained_grid(scene.poses[:4], scene.intrinsics)
+    g = m.density_grid[0].cpu().numpy()
+    from radnerf.scene import morton3d_np
+    centre = int(morton3d_np(np.array([64]), np.array([64]), np.array([64]))[0])
+    corner = int(morton3d_np(np.array([0]), np.array([127]), np.array([0]))[0])
+    assert g[centre] == 0 and g[corner] == -1 and 0.02 < (g == -1).mean() < 0.98
