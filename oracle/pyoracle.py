@@ -367,7 +367,7 @@ class Model:
         g.D, g.C, g.L = D, emb.shape[1], off.shape[0] - 1
         g.H = cfg.get("base_resolution", 16)
         g.S = float(np.log2(per_level_scale))
-        g.gridtype = cfg.get("gridtype", 1)
+        g.gridtype = cfg.get("gridtype_" + name, cfg.get("gridtype", 1))
         g.align_corners = 0
         g.interp = 0
         return g
@@ -470,7 +470,8 @@ def model_from_module(net):
     sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
     cfg = dict(per_level_scale_xyz=float(net.encoder.per_level_scale),
                per_level_scale_ambient=float(net.encoder_ambient.per_level_scale),
-               base_resolution=int(net.encoder.base_resolution), gridtype=int(net.encoder.gridtype_id),
+               base_resolution=int(net.encoder.base_resolution), gridtype=int(net.encoder_ambient.gridtype_id),
+               gridtype_encoder=int(net.encoder.gridtype_id),
                bound=float(net.bound), has_eye=bool(net.exp_eye), ind_dim=int(net.individual_dim),
                audio_dim=int(net.audio_dim), sh_degree=int(net.encoder_dir.degree))
     if getattr(net, "torso", False):

@@ -61,25 +61,64 @@ __device__ __forceinline__ void store_row(T *p, const T (&v)[C]) {
     }
 }
 
+// A gathered row kept as raw 32-bit words until it is blended: the loaders below hand their result over in plain
+// registers (no pointer punning on arrays), so a fetch in flight never has to live in scratch memory.
+template <typename T, uint32_t C>
+struct RowWords {
+    static constexpr uint32_t bytes = sizeof(T) * C;
+    static constexpr uint32_t W = (bytes + 3) / 4;
+    static_assert(bytes == 2 || bytes == 4 || bytes == 8 || bytes == 16 || bytes == 32, "unsupported row width");
+};
+
+template <typename T, uint32_t C>
+__device__ __forceinline__ void load_row_words(const T *p, uint32_t (&w)[RowWords<T, C>::W]) {
+    constexpr uint32_t bytes = RowWords<T, C>::bytes;
+    if constexpr (bytes == 2) {
+        w[0] = *reinterpret_cast<const uint16_t *>(p);
+    } else if constexpr (bytes == 4) {
+        w[0] = *reinterpret_cast<const uint32_t *>(p);
+    } else if constexpr (bytes == 8) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        w[0] = v.x, w[1] = v.y;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < bytes / 16; q++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(p)[q];
+            w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+        }
+    }
+}
+
 // Two adjacent rows with one load of 2*C scalars; the address is only guaranteed to be row-aligned
 // (C * sizeof(T)), which global loads on gfx950 accept (dword alignment is all the hardware needs).
 template <typename T, uint32_t C>
-__device__ __forceinline__ void load_pair(const T *p, T (&a)[C], T (&b)[C]) {
-    constexpr uint32_t bytes = sizeof(T) * C * 2;
+__device__ __forceinline__ void load_pair_words(const T *p, uint32_t (&a)[RowWords<T, C>::W], uint32_t (&b)[RowWords<T, C>::W]) {
+    constexpr uint32_t bytes = RowWords<T, C>::bytes * 2;
     constexpr uint32_t words = bytes / 4;
     if constexpr (bytes == 4) {  // two fp16 scalars
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
-        *reinterpret_cast<uint16_t *>(a) = (uint16_t)(w & 0xffffu);
-        *reinterpret_cast<uint16_t *>(b) = (uint16_t)(w >> 16);
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+        a[0] = v & 0xffffu;
+        b[0] = v >> 16;
     } else {
         typedef uint32_t vec_t __attribute__((ext_vector_type(words), aligned(4)));
         const vec_t v = *reinterpret_cast<const vec_t *>(p);
 #pragma unroll
         for (uint32_t i = 0; i < words / 2; i++) {
-            reinterpret_cast<uint32_t *>(a)[i] = v[i];
-            reinterpret_cast<uint32_t *>(b)[i] = v[words / 2 + i];
+            a[i] = v[i];
+            b[i] = v[words / 2 + i];
         }
     }
+}
+
+template <typename T> __device__ __forceinline__ T word_to(uint32_t w, uint32_t ch);
+template <> __device__ __forceinline__ float word_to<float>(uint32_t w, uint32_t) { return __uint_as_float(w); }
+template <> __device__ __forceinline__ __half word_to<__half>(uint32_t w, uint32_t ch) {
+    return __ushort_as_half((unsigned short)((ch & 1u) ? (w >> 16) : (w & 0xffffu)));
+}
+template <typename T, uint32_t C>
+__device__ __forceinline__ void unpack_row(const uint32_t (&w)[RowWords<T, C>::W], T (&v)[C]) {
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) v[ch] = word_to<T>(w[ch * sizeof(T) / 4], ch);
 }
 
 // gridencoder.cu:50-63
@@ -142,15 +181,19 @@ __device__ __forceinline__ void lattice_pos(const float (&in)[D], float scale, b
 // Splitting "issue" from "blend" lets a caller overlap the loads of level l+1 with the arithmetic of level l.
 template <typename T, uint32_t D, uint32_t C>
 struct LevelFetch {
-    T rows[1 << D][C];
+    uint32_t rows[1 << D][RowWords<T, C>::W];
     float pos[D], pos_deriv[D];
+    uint32_t swapped;  // bit (idx >> 1): rows[idx] and rows[idx + 1] arrived exchanged (hashed x-pairs, see issue_level)
 };
 
 
 // Compute the lattice position and the 2^D row indices of one sample at one level and ISSUE the row loads.
 // Index arithmetic (gridencoder.cu:66-84) is hoisted per dimension: (p + 1) * m == p * m + m (mod 2^32), so a
 // level costs D multiplies instead of D * 2^D.  On levels that are not hashed the two corners that differ only
-// in x sit in adjacent rows (unless the modulo wraps): one load of 2*C scalars fetches both.
+// in x sit in adjacent rows (unless the modulo wraps): one load of 2*C scalars fetches both.  On hashed levels the x
+// prime is 1 (gridencoder.cu:52), so for an even lattice x the two x-neighbours hash to rows r and r ^ 1 -- the two
+// halves of one aligned 2-row block (every level size is a multiple of 8, so the modulo keeps them together): one
+// aligned load fetches both, in table order; `swapped` tells blend_level which half is which.  Odd x: two loads.
 template <typename T, uint32_t D, uint32_t C>
 __device__ __forceinline__ void issue_level(const T *__restrict__ grid, const float (&in)[D], float scale,
                                             uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
@@ -181,6 +224,7 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ grid, const fl
     }
 
     constexpr bool kCanPair = sizeof(T) * C * 2 <= 32;
+    f.swapped = 0;
     if (!hashed) {
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx += 2) {
@@ -190,19 +234,27 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ grid, const fl
             const uint32_t row0 = fast_mod(base + t0[0], hashmap_size);
             const uint32_t row1 = fast_mod(base + t1[0], hashmap_size);
             if (kCanPair && row1 == row0 + 1) {
-                load_pair<T, C>(grid + (size_t)row0 * C, f.rows[idx], f.rows[idx + 1]);
+                load_pair_words<T, C>(grid + (size_t)row0 * C, f.rows[idx], f.rows[idx + 1]);
             } else {
-                load_row<T, C>(grid + (size_t)row0 * C, f.rows[idx]);
-                load_row<T, C>(grid + (size_t)row1 * C, f.rows[idx + 1]);
+                load_row_words<T, C>(grid + (size_t)row0 * C, f.rows[idx]);
+                load_row_words<T, C>(grid + (size_t)row1 * C, f.rows[idx + 1]);
             }
         }
     } else {
 #pragma unroll
-        for (uint32_t idx = 0; idx < (1u << D); idx++) {
-            uint32_t h = 0;
+        for (uint32_t idx = 0; idx < (1u << D); idx += 2) {
+            uint32_t base = 0;
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) h ^= ((idx >> d) & 1u) ? t1[d] : t0[d];
-            load_row<T, C>(grid + (size_t)fast_mod(h, hashmap_size) * C, f.rows[idx]);
+            for (uint32_t d = 1; d < D; d++) base ^= ((idx >> d) & 1u) ? t1[d] : t0[d];
+            const uint32_t row0 = fast_mod(base ^ t0[0], hashmap_size);
+            const uint32_t row1 = fast_mod(base ^ t1[0], hashmap_size);
+            if (kCanPair && (row0 ^ row1) == 1u) {
+                load_pair_words<T, C>(grid + (size_t)(row0 & ~1u) * C, f.rows[idx], f.rows[idx + 1]);
+                f.swapped |= (row0 & 1u) << (idx >> 1);
+            } else {
+                load_row_words<T, C>(grid + (size_t)row0 * C, f.rows[idx]);
+                load_row_words<T, C>(grid + (size_t)row1 * C, f.rows[idx + 1]);
+            }
         }
     }
 }
@@ -214,7 +266,30 @@ __device__ __forceinline__ void blend_level(const LevelFetch<T, D, C> &f, float 
                                             T (&grads)[DYDX ? D * C : 1]) {
     const float (&pos)[D] = f.pos;
     const float (&pos_deriv)[D] = f.pos_deriv;
-    const T (&rows)[1 << D][C] = f.rows;
+    // undo the exchange of hashed x-pairs so the corner order (and with it the summation order) is the reference's;
+    // the wave-uniform test keeps the selects off the levels that have none (every tiled / dense level)
+    constexpr uint32_t W = RowWords<T, C>::W;
+    T rows[1 << D][C];
+    if (__builtin_amdgcn_ballot_w64(f.swapped != 0u) != 0ull) {
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx += 2) {
+            // bit-select (v_bfi_b32) instead of ?: -- a select between two array elements invites the compiler to
+            // index the array dynamically, which would push the whole fetch into scratch
+            const uint32_t m = 0u - ((f.swapped >> (idx >> 1)) & 1u);
+            uint32_t lo[W], hi[W];
+#pragma unroll
+            for (uint32_t i = 0; i < W; i++) {
+                const uint32_t a = f.rows[idx][i], b = f.rows[idx + 1][i];
+                lo[i] = (a & ~m) | (b & m);
+                hi[i] = (b & ~m) | (a & m);
+            }
+            unpack_row<T, C>(lo, rows[idx]);
+            unpack_row<T, C>(hi, rows[idx + 1]);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) unpack_row<T, C>(f.rows[idx], rows[idx]);
+    }
 #pragma unroll
     for (uint32_t ch = 0; ch < C; ch++) results[ch] = from_f<T>(0.0f);
 #pragma unroll

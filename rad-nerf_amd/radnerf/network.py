@@ -99,7 +99,11 @@ class NeRFNetwork(NeRFRenderer):
             self.audio_att_net = AudioAttNet(self.audio_dim)
 
         grid = dict(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16, interpolation="linear")
-        self.encoder, self.in_dim = get_encoder("tiledgrid", input_dim=3, desired_resolution=2048 * self.bound, **grid)
+        # The reference hard-codes tiledgrid / T=2^16 for the xyz grid (nerf/network.py:70); `opt.xyz_grid` /
+        # `opt.xyz_log2_hashmap_size` select the instant-ngp hash variant (BASELINE config 1: hash, T=2^19) instead.
+        xyz_grid = dict(grid, log2_hashmap_size=int(getattr(opt, "xyz_log2_hashmap_size", 16)))
+        self.encoder, self.in_dim = get_encoder(getattr(opt, "xyz_grid", "tiledgrid"), input_dim=3,
+                                                desired_resolution=2048 * self.bound, **xyz_grid)
         self.encoder_ambient, self.in_dim_ambient = get_encoder("tiledgrid", input_dim=ambient_dim,
                                                                 desired_resolution=2048, **grid)
         self.num_layers_ambient, self.hidden_dim_ambient, self.ambient_dim = num_layers_ambient, hidden_dim_ambient, ambient_dim

@@ -101,6 +101,48 @@ def test_fused_frame_matches_oracle(po, hiplib, size):
         assert np.abs(gd[ok] - dep[ok]).max() <= 1e-3
 
 
+HASH19 = dict(xyz_grid="hashgrid", xyz_log2_hashmap_size=19)   # BASELINE config[1]
+
+
+@pytest.mark.parametrize("engine", ["fused", "ops"])
+def test_hash_grid_frame_matches_oracle(po, hiplib, engine):
+    """BASELINE config[1] names an instant-ngp hash grid with T=2^19 for xyz: levels 5..15 go through fast_hash
+    (gridencoder.cu:57-74, 98-99) instead of the tiled modulo."""
+    scene = _scene(64, engine, **HASH19)
+    assert scene.model.encoder.gridtype == "hash" and scene.model.encoder.embeddings.shape[0] > 16 * 2 ** 16
+    for i in range(2):
+        f = scene.frame(i)
+        with torch.no_grad():
+            out = scene.render(i)
+        img, dep, stats = _oracle_frame(po, scene, f, scene.model.enc_a)
+        got = out["image"].reshape(-1, 3).cpu().numpy()
+        assert np.abs(got - img).max() <= 2e-3, np.abs(got - img).max()
+        if engine == "fused":
+            st = scene.model.last_stats
+            assert st["iterations"] == stats["iterations"] and st["live_samples"] == stats["live_samples"]
+
+
+def test_hash_grid_fused_network_matches_oracle(po, hiplib):
+    from radnerf import fused
+    scene = _scene(16, "fused", **HASH19)
+    m = scene.model
+    rng = np.random.default_rng(19)
+    M = 20011
+    x = rng.uniform(-0.9, 0.9, (M, 3)).astype(np.float32)
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    enc_a = rng.standard_normal((1, 64)).astype(np.float32)
+    eye = np.array([[0.4]], np.float32)
+    c = m.individual_codes[1].detach()
+    with torch.no_grad():
+        sigma, color, amb = fused.network_forward(m, torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(),
+                                                  torch.from_numpy(enc_a).cuda(), c, torch.from_numpy(eye).cuda())
+    es, ec, ea = po.nerf_forward(po.model_from_module(m), x, d, enc_a, c.cpu().numpy(), eye)
+    np.testing.assert_allclose(amb.cpu().numpy(), ea, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), es, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(color.cpu().numpy(), ec, rtol=0, atol=2e-5)
+
+
 def test_fused_equals_ops_engine(hiplib):
     a, b = _scene(96, "fused"), _scene(96, "ops")
     for i in range(2):
