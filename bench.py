@@ -38,6 +38,12 @@ def parse():
     ap.add_argument("--engine", default=os.environ.get("RN_ENGINE", "auto"), choices=["auto", "ops", "fused"])
     ap.add_argument("--grid", default="hash19", choices=sorted(GRIDS),
                     help="xyz grid: hash19 = BASELINE config[1] (hash, T=2^19); tiled16 = the reference's shipped model")
+    ap.add_argument("--workload", default="render", choices=["render", "tile", "train"],
+                    help="render = BASELINE config[1]/[3] (the headline metric, frame-parallel); tile = config[4], ONE "
+                         "1024x1024 frame split over the ranks in interleaved row bands (pass --size 1024); train = "
+                         "config[2], one optimisation step of 4096 rays (march_rays_train + network + "
+                         "composite_rays_train, backward, Adam)")
+    ap.add_argument("--rays", type=int, default=4096, help="rays per training step (--workload train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -110,8 +116,67 @@ def cpu_baseline(scene_kwargs, size, opt_overrides):
                 samples_per_s=stats["live_samples"] * reps / dt)
 
 
+def run_train(args):
+    """BASELINE config[2] on one GPU: steps/s and samples/s of Trainer.step (radnerf/train.py) on 4096 random rays of
+    frame 0, head model (torso off, as the reference trains the head), perturb on, occupancy grid refreshed every 16
+    steps inside the timed region.  A secondary line: the headline metric stays the render workload."""
+    torch.cuda.set_device(0)
+    import radnerf_hip as hip
+    from radnerf.scene import SyntheticScene, default_opt
+    from radnerf.train import SyntheticTrainStream, Trainer
+    size, K, W = args.size, args.steps, args.warmup
+    scene = SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine="ops", torso=False, **GRIDS[args.grid]))
+    stream = SyntheticTrainStream(scene, n_rays=args.rays)
+    trainer = Trainer(scene.model, scene.opt)
+    m = scene.model
+    for _ in range(max(W, 17)):          # past the first grid refresh, so mean_count is warm (SURVEY 8(d) config 2)
+        trainer.step(stream.batch())
+    acc = {}
+
+    def sel(name, a):
+        if name == "rn_grid_encode_backward" and a[6] == 3:     # (grad, inputs, table, offsets, grad_table, B, D, ...)
+            acc["n"] = acc.get("n", 0.0) + float(a[5])
+            return "grid_encode_backward_xyz"
+        return None
+    timer = hip.KernelTimer(sel)
+    hip.set_timer(timer)
+    samples = torch.zeros((), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(K):
+        losses.append(trainer.step(stream.batch()))
+        samples += m.step_counter[(m.local_step - 1) % 16, 0]        # samples marched by this step (stays on the device)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    hip.set_timer(None)
+    samples = int(samples.item())
+    res = timer.results().get("grid_encode_backward_xyz")
+    roof = None
+    if res:
+        # scatter-add of 16 levels x 8 corners x 8 B (atomic read-modify-write counted once) + 128 B grad + 12 B coords
+        per_launch = acc["n"] / res["launches"] * (1024 + 128 + 12)
+        ach = per_launch / (res["avg_ms"] * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel="k_grid_bwd_table (xyz grid scatter-add)", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=ach / HBM_PEAK_GBS, traffic=None, launches=res["launches"], avg_launch_ms=res["avg_ms"],
+                    algorithmic_bytes_per_launch=per_launch, share_of_step=res["total_ms"] / (elapsed * 1e3),
+                    note="a training step is launch-latency bound (~65 k samples); no kernel is near a roof")
+    print(json.dumps({
+        "metric": "training steps/sec @4096 rays", "value": K / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": max(W, 17),
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"config[2]: single-GPU training step, {args.rays} rays of a {size}x{size} frame, {GRID_TEXT[args.grid]}, "
+                               "march_rays_train + network + composite_rays_train fwd/bwd + grid_encode backward + Adam, "
+                               "update_extra_state every 16 steps (inside the timed region)", "grid": args.grid},
+        "samples_per_s": samples / elapsed, "samples_per_step": samples / K,
+        "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "roofline": roof}))
+
+
 def main():
     args = parse()
+    if args.workload == "train":
+        assert args.gpus == 1, "training is replicas-only (SURVEY 8(e)); run --workload train with --gpus 1"
+        return run_train(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,7 +193,7 @@ def main():
 
     import radnerf_hip as hip
     from radnerf.scene import SyntheticScene, default_opt
-    from radnerf.parallel import FrameParallelRenderer
+    from radnerf.parallel import FrameParallelRenderer, TileParallelRenderer
 
     engine = pick_engine(args.engine)
     size = args.size
@@ -136,7 +201,8 @@ def main():
     n_frames = 250
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
                            opt=default_opt(engine=engine, **GRIDS[args.grid]))
-    fpr = FrameParallelRenderer(scene, rank, world, dist)
+    tile = args.workload == "tile"
+    fpr = (TileParallelRenderer if tile else FrameParallelRenderer)(scene, rank, world, dist)
 
     def barrier():
         if dist is not None:
@@ -177,7 +243,7 @@ def main():
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    total_frames = K * world
+    total_frames = K if tile else K * world       # tile-parallel: every rank works on the same K frames
     fps = total_frames / elapsed
 
     if rank == 0:
@@ -212,13 +278,17 @@ def main():
                         avg_launch_ms=r["avg_ms"], algorithmic_bytes_per_launch=per_launch_bytes,
                         share_of_step=r["total_ms"] / (elapsed * 1e3))
         out = {
-            "metric": "rendered frames/sec @512x512", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": f"rendered frames/sec @{size}x{size}", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if tile else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config[1]: single-GPU inference {size}x{size}, {GRID_TEXT[args.grid]}, "
+            "config": {"workload": (f"config[4]: tile-parallel single {size}x{size} frame, interleaved 8-row bands, " if tile else
+                                    f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "
                                    "max 16 steps/ray, 25 FPS pose stream, torso pass on",
-                       "grid": args.grid, "engine": engine, "frames_per_gpu": K, "parallelism": f"frame-parallel x{world}"},
-            "samples_per_s": live_pf * fps, "samples_per_frame": live_pf, "sample_slots_per_frame": slots_pf,
+                       "grid": args.grid, "engine": engine, "frames_per_gpu": K,
+                       "parallelism": f"{'tile' if tile else 'frame'}-parallel x{world}"},
+            # tile-parallel: rank 0 counts its own band's samples; the bands are interleaved, so x world is the frame's
+            "samples_per_s": live_pf * (world if tile else 1) * fps, "samples_per_frame": live_pf * (world if tile else 1),
+            "sample_slots_per_frame": slots_pf * (world if tile else 1),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

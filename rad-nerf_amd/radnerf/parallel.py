@@ -1,4 +1,7 @@
-"""Frame-parallel rendering across the GPUs of one node (BASELINE config 3).
+"""Frame-parallel (BASELINE config 3) and tile-parallel (config 4) rendering across the GPUs of one node
+(SURVEY §8(e)).
+
+Frame-parallel:
 
 One process per GPU.  Rank r renders global frames r, r + W, r + 2W, ... of the pose/audio stream; the
 weights, tables and occupancy bitfield (~16 MB) are replicated.  The only cross-frame state of the path is
@@ -6,6 +9,12 @@ the lip-smoothing EMA of the audio code (nerf/renderer.py:190-194); a rank there
 windows of the frames it skips (one batched AudioNet pass) and folds them into its EMA state before it
 renders, which reproduces the sequential result exactly.  The only collective is the gather of finished
 frames (uint8, 786 KB at 512^2) over RCCL; it is issued asynchronously so it overlaps the next frame.
+
+Tile-parallel: ONE frame is split over the ranks in interleaved bands of `band` image rows (the head sits in the
+centre of the image, so contiguous bands would leave the outer ranks idle).  Every stage of the path is per pixel
+-- head march/composite, torso pass, blend (nerf/renderer.py:225-311) -- so a rank runs the whole path on its own
+pixels and the only exchange is the gather of finished uint8 rows; every rank advances the audio EMA itself, so
+there is no other shared state.
 """
 import json
 import os
@@ -27,7 +36,48 @@ def skipped_frames(step, rank, world):
     return list(range(first, g))
 
 
-class FrameParallelRenderer:
+class _Bookkeeping:
+    """What bench.py reads from either renderer."""
+
+    # -- bookkeeping for bench.py -------------------------------------------------------------------
+    def loop_counters(self):
+        """Cumulative (iterations, live samples, sample slots) of the fused engine's device-side loop, or None."""
+        try:
+            from . import fused
+        except ImportError:
+            return None
+        return fused.loop_counters(self.scene.model)
+
+    def count_samples(self, steps):
+        """Untimed replay of `steps` with the per-iteration live-sample count switched on; returns the mean
+        number of live samples (deltas[:,0] > 0) and of padded sample slots per frame."""
+        m = self.scene.model
+        live = slots = 0
+        m.count_samples = True
+        try:
+            for s in steps:
+                self._render_for_count(s)
+                live += m.last_stats["live_samples"]
+                slots += m.last_stats["sample_slots"]
+        finally:
+            m.count_samples = False
+        return live / max(len(steps), 1), slots / max(len(steps), 1)
+
+    @staticmethod
+    def measured_traffic(key):
+        """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), else None."""
+        p = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles",
+                         "traffic.json")
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)).get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                return None
+        return None
+
+
+
+class FrameParallelRenderer(_Bookkeeping):
     def __init__(self, scene, rank=0, world=1, dist=None, gather=True):
         self.scene, self.rank, self.world, self.dist = scene, rank, world, dist
         self.gather = gather and dist is not None and world > 1
@@ -65,6 +115,9 @@ class FrameParallelRenderer:
         self.last_frame = u8
         return u8
 
+    def _render_for_count(self, step):
+        self.scene.render(frame_of(step, self.rank, self.world))
+
     def finish(self):
         """Wait for every outstanding gather; returns the gathered [world, H, W, 3] uint8 stacks in step order."""
         done = []
@@ -76,38 +129,80 @@ class FrameParallelRenderer:
         self.pending = []
         return done
 
-    # -- bookkeeping for bench.py -------------------------------------------------------------------
-    def loop_counters(self):
-        """Cumulative (iterations, live samples, sample slots) of the fused engine's device-side loop, or None."""
-        try:
-            from . import fused
-        except ImportError:
-            return None
-        return fused.loop_counters(self.scene.model)
 
-    def count_samples(self, steps):
-        """Untimed replay of `steps` with the per-iteration live-sample count switched on; returns the mean
-        number of live samples (deltas[:,0] > 0) and of padded sample slots per frame."""
-        m = self.scene.model
-        live = slots = 0
-        m.count_samples = True
-        try:
-            for s in steps:
-                self.scene.render(frame_of(s, self.rank, self.world))
-                live += m.last_stats["live_samples"]
-                slots += m.last_stats["sample_slots"]
-        finally:
-            m.count_samples = False
-        return live / max(len(steps), 1), slots / max(len(steps), 1)
+def stripe_rows(H, rank, world, band=8):
+    """Image rows owned by `rank`: bands of `band` consecutive rows dealt round-robin over the ranks."""
+    rows = torch.arange(H)
+    return rows[(rows // band) % world == rank]
 
-    @staticmethod
-    def measured_traffic(key):
-        """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), else None."""
-        p = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles",
-                         "traffic.json")
-        if os.path.exists(p):
-            try:
-                return json.load(open(p)).get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                return None
-        return None
+
+class TileParallelRenderer(_Bookkeeping):
+    """BASELINE config 4 (a single 1024^2 frame over 8 GPUs).  `step(i)` renders this rank's rows of global frame i
+    and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (identical on every rank)."""
+
+    def __init__(self, scene, rank=0, world=1, dist=None, band=8):
+        self.scene, self.rank, self.world, self.dist, self.band = scene, rank, world, dist, band
+        H, W = scene.H, scene.W
+        self.rows = [stripe_rows(H, r, world, band) for r in range(world)]
+        self.n_max = max(len(r) for r in self.rows)
+        mine = self.rows[rank].to(scene.device)
+        self.pix = (mine[:, None] * W + torch.arange(W, device=scene.device)[None, :]).reshape(-1)   # row-major ray ids
+        self.pending = []
+        self._static = None     # this rank's slice of the per-pixel inputs that do not change with the frame
+        self._rays = {}
+
+    def _inputs(self, i):
+        sc, px = self.scene, self.pix
+        f = sc.frame(i)
+        if self._static is None:
+            self._static = (f["bg_coords"][:, px].contiguous(), f["bg_color"][:, px].contiguous())
+        key = i % getattr(sc, "n_frames", 1 << 30)
+        if key not in self._rays:
+            self._rays[key] = (f["rays_o"][:, px].contiguous(), f["rays_d"][:, px].contiguous())
+        return f, self._rays[key], self._static
+
+    def render_local(self, i):
+        """This rank's pixels of frame i through the scene's model: [n_rows, W, 3] uint8."""
+        sc = self.scene
+        f, (rays_o, rays_d), (bg_coords, bg_color) = self._inputs(i)
+        out = sc.model.render(rays_o, rays_d, f["auds"], bg_coords, f["poses"], eye=f["eye"], index=f["index"],
+                              bg_color=bg_color, **sc.render_kwargs())
+        return (out["image"].reshape(-1, sc.W, 3) * 255).to(torch.uint8)
+
+    def _render_for_count(self, step):
+        self.render_local(step)
+
+    def step(self, i):
+        u8 = self.render_local(i)
+        if self.dist is None or self.world == 1:
+            self.pending.append((None, None, u8))
+            return u8
+        send = u8
+        if u8.shape[0] < self.n_max:                     # ragged last band: pad so one fixed-size gather does it
+            send = torch.cat([u8, u8.new_zeros((self.n_max - u8.shape[0],) + tuple(u8.shape[1:]))])
+        buf = torch.empty((self.world,) + tuple(send.shape), dtype=torch.uint8, device=u8.device)
+        if self.dist.get_backend() == "nccl":
+            work = self.dist.all_gather_into_tensor(buf, send.contiguous(), async_op=True)
+        else:
+            work = self.dist.all_gather(list(buf.unbind(0)), send.contiguous(), async_op=True)
+        self.pending.append((work, buf, send))
+        return u8
+
+    def assemble(self, buf):
+        sc = self.scene
+        frame = torch.empty((sc.H, sc.W, 3), dtype=torch.uint8, device=buf.device)
+        for r in range(self.world):
+            rows = self.rows[r].to(buf.device)
+            frame[rows] = buf[r, :len(rows)]
+        return frame
+
+    def finish(self):
+        frames = []
+        for work, buf, u8 in self.pending:
+            if work is None:
+                frames.append(self.assemble(u8[None]))
+            else:
+                work.wait()
+                frames.append(self.assemble(buf))
+        self.pending = []
+        return frames

@@ -1,0 +1,95 @@
+"""One training step of the render path (BASELINE config 2): the train branch of run_cuda
+(march_rays_train -> NeRFNetwork.forward -> composite_rays_train, all over the HIP operators and their
+backward kernels), the reference's loss and its Adam parameter groups.
+
+Reference: Trainer.train_step (nerf/utils.py:718-806) for the loss, Trainer.train_one_epoch (:1003-1040) for
+the order zero_grad -> step -> backward -> optimizer and the `update_extra_state` cadence
+(`--update_extra_interval 16`, main.py:31), main.py:204 for Adam(betas=(0.9, 0.99), eps=1e-15) over
+NeRFNetwork.get_params(lr, lr_net) (nerf/network.py:328-357).  The data loader, LPIPS, EMA, GradScaler and the
+learning-rate schedule are outside the path (out of scope) and are not rebuilt.
+"""
+import torch
+
+
+def make_optimizer(model, lr=5e-3, lr_net=5e-4):
+    """main.py:204; lr for the grid tables, lr_net for the MLPs / audio nets / individual codes."""
+    return torch.optim.Adam(model.get_params(lr, lr_net), betas=(0.9, 0.99), eps=1e-15)
+
+
+def entropy_of(alphas):
+    """nerf/utils.py:785-794: binary entropy that pushes an opacity towards 0 or 1."""
+    a = alphas.clamp(1e-5, 1 - 1e-5)
+    return -a * torch.log2(a) - (1 - a) * torch.log2(1 - a)
+
+
+def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1):
+    """-> (pred_rgb, target_rgb, loss); `data` has the keys of the reference's loader batch
+    (nerf/provider.py:588-690): rays_o, rays_d [B,N,3], bg_coords [1,N,2], poses [B,6], face_mask [B,N],
+    eye [B,1], auds, index, bg_color [B,N,3], images (head) or bg_torso_color (torso) [B,N,3]."""
+    torso = bool(opt.torso)
+    rgb = data["bg_torso_color"] if torso else data["images"]
+    out = model.render(data["rays_o"], data["rays_d"], data["auds"], data["bg_coords"], data["poses"], eye=data["eye"],
+                       index=data["index"], staged=False, bg_color=data["bg_color"], perturb=True, force_all_rays=False,
+                       dt_gamma=opt.dt_gamma, max_steps=opt.max_steps)
+    pred = out["torso_color"] if torso else out["image"]
+    loss = torch.nn.functional.mse_loss(pred, rgb, reduction="none").mean(-1).mean()
+    if torso:
+        loss = loss + 1e-4 * entropy_of(out["torso_alpha"]).mean()
+    else:
+        loss = loss + 1e-4 * entropy_of(out["weights_sum"]).mean()
+        # ambient coordinates should stay put outside the face (nerf/utils.py:796-803), weight ramped over `iters`
+        loss_amb = (out["ambient"] * (~data["face_mask"].view(-1))).mean()
+        loss = loss + min(global_step / iters, 1.0) * lambda_amb * loss_amb
+    return pred, rgb, loss
+
+
+class SyntheticTrainStream:
+    """Batches of `n_rays` random pixels of a SyntheticScene frame with the scene's own frozen render as target
+    (SURVEY 8(d) config 2); everything stays on the device."""
+
+    def __init__(self, scene, n_rays=4096, frame=0, seed=0):
+        self.scene, self.n_rays, self.frame = scene, n_rays, frame
+        self.gen = torch.Generator(device=scene.device).manual_seed(seed)
+        m = scene.model
+        was_training = m.training
+        m.eval()
+        with torch.no_grad():
+            out = scene.render(frame)
+        m.train(was_training)
+        self.f = scene.frame(frame)
+        self.target = out["image"].reshape(1, -1, 3).clamp(0, 1).detach().clone()
+        self.face_mask = torch.nan_to_num(out["depth"].reshape(1, -1), nan=0.0) > 0   # "face" = pixels the head covers
+        # what update_extra_state samples from (main.py:183-186 hands the loader's arrays to the model)
+        m.aud_features, m.poses = scene.aud_features, scene.poses
+        m.eye_area = torch.full((scene.n_frames, 1), 0.25, device=scene.device)
+
+    def batch(self):
+        f, n_px = self.f, self.target.shape[1]
+        idx = torch.randint(0, n_px, (self.n_rays,), device=self.target.device, generator=self.gen)
+        return dict(rays_o=f["rays_o"][:, idx], rays_d=f["rays_d"][:, idx], bg_coords=f["bg_coords"][:, idx], poses=f["poses"],
+                    face_mask=self.face_mask[:, idx], eye=f["eye"], auds=f["auds"], index=[self.frame],
+                    bg_color=f["bg_color"][:, idx], images=self.target[:, idx], bg_torso_color=self.target[:, idx])
+
+
+class Trainer:
+    """zero_grad -> train_step -> backward -> Adam, with the occupancy grid refreshed every
+    `update_extra_interval` steps as the reference's loop does under --cuda_ray (nerf/utils.py:1015-1018)."""
+
+    def __init__(self, model, opt, lr=5e-3, lr_net=5e-4, update_extra_interval=16, iters=200000, lambda_amb=0.1):
+        self.model, self.opt = model, opt
+        self.optimizer = make_optimizer(model, lr, lr_net)
+        self.update_extra_interval, self.iters, self.lambda_amb = update_extra_interval, iters, lambda_amb
+        self.global_step = 0
+
+    def step(self, data):
+        m = self.model
+        m.train()
+        if self.update_extra_interval and self.global_step % self.update_extra_interval == 0:
+            with torch.no_grad():
+                m.update_extra_state()
+        self.global_step += 1
+        self.optimizer.zero_grad(set_to_none=True)
+        _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()

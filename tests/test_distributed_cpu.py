@@ -118,3 +118,67 @@ def test_skipped_frames_partition():
             for s in range(5):
                 seen += skipped_frames(s, rank, world) + [frame_of(s, rank, world)]
             assert seen == list(range(frame_of(4, rank, world) + 1))  # every frame's audio is folded exactly once, in order
+
+
+# ---- tile-parallel (BASELINE config 4): one frame split in interleaved row bands -------------------------------
+
+class _PixelModel:
+    """Per-pixel stand-in for NeRFRenderer.render: every output pixel depends only on its own ray, bg coordinate and
+    bg colour -- the property of the real path that tile-parallel rendering relies on (nerf/renderer.py:225-311)."""
+
+    def render(self, rays_o, rays_d, auds, bg_coords, poses, eye=None, index=0, bg_color=None, **kw):
+        v = torch.sigmoid(3 * rays_d[..., :1] + bg_coords[..., :1] * 0.7 + poses.sum() * 0.01 + auds.mean())
+        return {"image": (v * bg_color * torch.tensor([1.0, 0.8, 0.6])).clamp(0, 1)}
+
+
+class _TileScene:
+    def __init__(self, Hh, Ww):
+        from types import SimpleNamespace
+        self.H, self.W, self.device = Hh, Ww, torch.device("cpu")
+        g = torch.Generator().manual_seed(1)
+        self.rays_d = torch.randn(1, Hh * Ww, 3, generator=g)
+        self.bg_coords = torch.rand(1, Hh * Ww, 2, generator=g)
+        self.bg_color = torch.rand(1, Hh * Ww, 3, generator=g)
+        self.model = _PixelModel()
+
+    def frame(self, i):
+        return dict(rays_o=torch.zeros_like(self.rays_d), rays_d=self.rays_d + 0.01 * i, auds=torch.full((8, 4, 16), 0.1 * i),
+                    bg_coords=self.bg_coords, poses=torch.ones(1, 6), eye=None, index=0, bg_color=self.bg_color)
+
+    def render_kwargs(self):
+        return {}
+
+
+def _tile_worker(rank, world, port, Hh, Ww, band, ret):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from radnerf.parallel import TileParallelRenderer
+    tpr = TileParallelRenderer(_TileScene(Hh, Ww), rank, world, dist, band=band)
+    for i in range(2):
+        tpr.step(i)
+    ret[rank] = [f.numpy() for f in tpr.finish()]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Hh,band", [(2, 16, 4), (3, 20, 4), (2, 10, 8)])   # even split, ragged split, short last band
+def test_tile_parallel_equals_whole_frame(hiplib, world, Hh, band):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
+    from radnerf.parallel import TileParallelRenderer, stripe_rows
+    Ww = 12
+    rows = torch.cat([stripe_rows(Hh, r, world, band) for r in range(world)])
+    assert sorted(rows.tolist()) == list(range(Hh))                      # the bands partition the image
+    whole = TileParallelRenderer(_TileScene(Hh, Ww), 0, 1, None, band=band)
+    for i in range(2):
+        whole.step(i)
+    expect = [f.numpy() for f in whole.finish()]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tile_worker, args=(world, _free_port(), Hh, Ww, band, ret), nprocs=world, join=True)
+    for rank in range(world):
+        for i in range(2):
+            assert np.array_equal(ret[rank][i], expect[i]), (rank, i)

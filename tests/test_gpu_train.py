@@ -151,3 +151,34 @@ def test_update_extra_state_torso_and_mark_untrained(hiplib, monkeypatch):
     centre = int(morton3d_np(np.array([64]), np.array([64]), np.array([64]))[0])
     corner = int(morton3d_np(np.array([0]), np.array([127]), np.array([0]))[0])
     assert g[centre] == 0 and g[corner] == -1 and 0.02 < (g == -1).mean() < 0.98
+
+
+def test_trainer_steps_reduce_the_loss(hiplib):
+    """BASELINE config 2 as a loop: Trainer.step = update_extra_state cadence + train_step + backward + Adam
+    (nerf/utils.py:718-806, 1003-1040; main.py:204).  Target = the scene's own frozen render, so a perturbed copy
+    of the model must move back towards it."""
+    from radnerf.train import SyntheticTrainStream, Trainer
+    scene = _scene(64, torso=False)
+    stream = SyntheticTrainStream(scene, n_rays=2048)
+    m = scene.model
+    with torch.no_grad():                       # knock the colour head off target
+        m.color_net.net[-1].weight.add_(0.3 * torch.randn_like(m.color_net.net[-1].weight))
+    trainer = Trainer(m, scene.opt, update_extra_interval=0)     # keep the ellipsoid occupancy (a3 has its own tests)
+    losses = [float(trainer.step(stream.batch())) for _ in range(40)]
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+    assert int(m.step_counter[:, 0].max()) > 0 and m.local_step == 40
+
+
+def test_trainer_refreshes_occupancy_every_interval(hiplib):
+    from radnerf.train import SyntheticTrainStream, Trainer
+    scene = _scene(32, torso=False)
+    stream = SyntheticTrainStream(scene, n_rays=512)
+    m = scene.model
+    trainer = Trainer(m, scene.opt, update_extra_interval=4)
+    before = m.density_bitfield.clone()
+    for _ in range(5):
+        loss = trainer.step(stream.batch())
+    assert torch.isfinite(loss)
+    assert m.local_step == 1                    # reset by the refresh before step 5 (renderer.py:499), then one step
+    assert m.mean_count > 0 and not torch.equal(before, m.density_bitfield)
