@@ -125,7 +125,7 @@ def run_train(args):
     from radnerf.scene import SyntheticScene, default_opt
     from radnerf.train import SyntheticTrainStream, Trainer
     size, K, W = args.size, args.steps, args.warmup
-    scene = SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine="ops", torso=False, **GRIDS[args.grid]))
+    scene = SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine="ops", torso=False, smooth_lips=False, **GRIDS[args.grid]))
     stream = SyntheticTrainStream(scene, n_rays=args.rays)
     trainer = Trainer(scene.model, scene.opt)
     m = scene.model

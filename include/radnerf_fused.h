@@ -100,6 +100,15 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream);
  * (step >= max_steps or no ray alive) are no-ops decided on the device. */
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
                     const float *bias, uint32_t first_iter, uint32_t n_iters, rn_stream_t stream);
+/* Step schedule of a SHARD of a frame (tile-parallel rendering, BASELINE config 4).  The reference's policy
+ * n_step = max(min(N // n_alive, 8), 1) (nerf/renderer.py:249) uses the ray count and the live count of the whole
+ * call; a rank that renders only a band of the image reproduces the whole-frame schedule (and so the whole-frame
+ * pixels: `step += n_step` may overshoot max_steps, so the schedule is visible in the image) by calling this after
+ * iteration `iter_done` with schedule_N = rays of the whole frame and *alive_total = live rays of the whole frame
+ * for the coming iteration (the all-reduced sum of each rank's state[((iter_done + 1) & 1) * 8 + 0]).  Only
+ * n_step and the slot count of the coming iteration are rewritten; everything stays on the device. */
+int rn_head_reschedule(const rn_head_t *h, uint32_t iter_done, uint32_t schedule_N, const int32_t *alive_total,
+                       rn_stream_t stream);
 /* Layout of h->state (int32 words).  Words 0..15 are the loop state, reset by rn_head_begin; words 16.. are
  * statistics that ACCUMULATE across frames (wrapping int32; the caller zeroes them when it wants to). */
 #define RN_HEAD_ST_ACTIVE 4      /* state[(iter & 1) * 8 + 4]: 1 while the loop wants another iteration */

@@ -594,6 +594,18 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
         next_state(st_next, N, offset + total, (uint32_t)st[1] + (uint32_t)st[2], max_steps);
 }
 
+// Whole-frame step schedule for a shard of the frame (see radnerf_fused.h): same policy as next_state, fed with the
+// frame-wide ray and live counts.
+__global__ void k_head_reschedule(int32_t *__restrict__ st, uint32_t schedule_N, const int32_t *__restrict__ alive_total) {
+    if (threadIdx.x != 0 || !st[4]) return;
+    const uint32_t total = (uint32_t)alive_total[0];
+    uint32_t n_step = total ? schedule_N / total : 1u;
+    n_step = n_step > 8u ? 8u : n_step;
+    n_step = n_step < 1u ? 1u : n_step;
+    st[2] = (int32_t)n_step;
+    st[3] = (int32_t)((uint32_t)st[0] * n_step);
+}
+
 // ==========================================================================================================
 // Torso pass (nerf/renderer.py:269-299, nerf/network.py:188-219) and final blend (renderer.py:306-311)
 //
@@ -1000,6 +1012,15 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
                            h->block_counts);
     }
     return check_launch("head_iterate");
+}
+
+int rn_head_reschedule(const rn_head_t *h, uint32_t iter_done, uint32_t schedule_N, const int32_t *alive_total,
+                       rn_stream_t stream) {
+    if (int rc = check_head(h)) return rc;
+    RN_REQUIRE(alive_total && schedule_N >= h->N, "head_reschedule: alive_total is null or schedule_N < N");
+    hipLaunchKernelGGL(k_head_reschedule, dim3(1), dim3(64), 0, as_stream(stream), h->state + ((iter_done + 1) & 1u) * 8,
+                       schedule_N, alive_total);
+    return check_launch("head_reschedule");
 }
 
 size_t rn_torso_packed_floats(void) { return (size_t)kTorsoPacked; }

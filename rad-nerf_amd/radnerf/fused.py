@@ -59,6 +59,7 @@ _SIGS = {
                               _ptr, _ptr, _ptr],
     "rn_head_begin": [C.POINTER(HeadT), _ptr],
     "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, _ptr],
+    "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
     "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
     "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
                        _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -286,8 +287,22 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     # The whole <= max_steps loop is enqueued without reading anything back: iterations past the end of the loop
     # are no-ops decided on the device (a few microseconds each), so the host can run ahead of the GPU.
     hip.call("rn_head_begin", C.byref(h), s)
-    hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0,
-             int(max_steps), s)
+    shard = getattr(model, "shard_schedule", None)
+    if shard is None:
+        hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0,
+                 int(max_steps), s)
+    else:
+        # This call renders a shard of a frame (tile-parallel): the step schedule must be the whole frame's, so the
+        # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.
+        group, n_total = shard
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        for it in range(int(max_steps)):
+            hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias),
+                     it, 1, s)
+            bank = ((it + 1) & 1) * 8
+            total.copy_(st.state[bank:bank + 1])
+            group.all_reduce(total)
+            hip.call("rn_head_reschedule", C.byref(h), it, int(n_total), hip.ptr(total), hip.stream())
 
     # torso layer over the background
     bg_in = None

@@ -13,8 +13,12 @@ frames (uint8, 786 KB at 512^2) over RCCL; it is issued asynchronously so it ove
 Tile-parallel: ONE frame is split over the ranks in interleaved bands of `band` image rows (the head sits in the
 centre of the image, so contiguous bands would leave the outer ranks idle).  Every stage of the path is per pixel
 -- head march/composite, torso pass, blend (nerf/renderer.py:225-311) -- so a rank runs the whole path on its own
-pixels and the only exchange is the gather of finished uint8 rows; every rank advances the audio EMA itself, so
-there is no other shared state.
+pixels and the only bulk exchange is the gather of finished uint8 rows; every rank advances the audio EMA itself.
+One scalar is shared: the reference's step policy n_step = max(min(N // n_alive, 8), 1) (renderer.py:249) looks at
+the live-ray count of the whole call, and because `step += n_step` can overshoot max_steps the schedule shows in
+the pixels.  With schedule="frame" (default) the ranks therefore sum their live counts between loop iterations
+(a 4-byte all-reduce enqueued on the device, no host read-back), which makes the assembled frame equal to a
+single-GPU render of the whole image; schedule="band" skips it.
 """
 import json
 import os
@@ -140,8 +144,15 @@ class TileParallelRenderer(_Bookkeeping):
     """BASELINE config 4 (a single 1024^2 frame over 8 GPUs).  `step(i)` renders this rank's rows of global frame i
     and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (identical on every rank)."""
 
-    def __init__(self, scene, rank=0, world=1, dist=None, band=8):
+    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule="frame"):
+        """schedule="frame": the ranks agree on the whole frame's step schedule (one 4-byte all-reduce per loop
+        iteration, enqueued on the device; fused engine) so the assembled image IS the whole-frame render;
+        schedule="band": no collective inside the loop, each band follows the reference's policy for its own rays."""
         self.scene, self.rank, self.world, self.dist, self.band = scene, rank, world, dist, band
+        if schedule == "frame" and dist is not None and world > 1:
+            if getattr(scene.opt, "engine", "ops") != "fused":
+                raise RuntimeError("schedule='frame' needs the fused engine (device-resident loop state)")
+            scene.model.shard_schedule = (dist, scene.H * scene.W)
         H, W = scene.H, scene.W
         self.rows = [stripe_rows(H, r, world, band) for r in range(world)]
         self.n_max = max(len(r) for r in self.rows)
@@ -180,8 +191,11 @@ class TileParallelRenderer(_Bookkeeping):
         send = u8
         if u8.shape[0] < self.n_max:                     # ragged last band: pad so one fixed-size gather does it
             send = torch.cat([u8, u8.new_zeros((self.n_max - u8.shape[0],) + tuple(u8.shape[1:]))])
-        buf = torch.empty((self.world,) + tuple(send.shape), dtype=torch.uint8, device=u8.device)
-        if self.dist.get_backend() == "nccl":
+        nccl = self.dist.get_backend() == "nccl"
+        if not nccl:
+            send = send.cpu()                            # gloo gathers host tensors (CPU tests, 1-GPU rehearsals)
+        buf = torch.empty((self.world,) + tuple(send.shape), dtype=torch.uint8, device=send.device)
+        if nccl:
             work = self.dist.all_gather_into_tensor(buf, send.contiguous(), async_op=True)
         else:
             work = self.dist.all_gather(list(buf.unbind(0)), send.contiguous(), async_op=True)

@@ -58,7 +58,8 @@ class SyntheticTrainStream:
         m.train(was_training)
         self.f = scene.frame(frame)
         self.target = out["image"].reshape(1, -1, 3).clamp(0, 1).detach().clone()
-        self.face_mask = torch.nan_to_num(out["depth"].reshape(1, -1), nan=0.0) > 0   # "face" = pixels the head covers
+        # "face" = pixels the head layer changed (the loader's face_mask comes from a parsing net, provider.py:199-215)
+        self.face_mask = (self.target - self.f["bg_color"].reshape(1, -1, 3)).abs().sum(-1) > 1e-3
         # what update_extra_state samples from (main.py:183-186 hands the loader's arrays to the model)
         m.aud_features, m.poses = scene.aud_features, scene.poses
         m.eye_area = torch.full((scene.n_frames, 1), 0.25, device=scene.device)

@@ -1,6 +1,10 @@
-"""BASELINE config 4 on one GPU: the bands a TileParallelRenderer rank renders, put back together, are the frame a
-single whole-image render gives (every stage of the path is per pixel, nerf/renderer.py:225-311).  Ranks are emulated
-one after the other in this process; the gather itself is covered by the gloo tests in test_distributed_cpu.py."""
+"""BASELINE config 4 on one GPU: the bands a TileParallelRenderer rank renders.  Every stage of the path is per pixel
+(nerf/renderer.py:225-311), with one caveat the reference itself has: the inference loop's step schedule
+`n_step = max(min(N // n_alive, 8), 1)` (renderer.py:241) depends on the number of rays in the call, and a ray may
+receive more than max_steps samples under one schedule and fewer under another (`step += n_step` overshoots).  So
+  * a band equals what the reference semantics give FOR THAT BAND's rays (strict check against the oracle), and
+  * the reassembled frame equals the whole-image render up to that schedule effect (rare pixels, a few 1/255).
+Ranks are emulated one after the other in this process; the gather is covered by the gloo tests."""
 import numpy as np
 import pytest
 import torch
@@ -10,11 +14,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("engine", ["fused", "ops"])
 @pytest.mark.parametrize("world,size", [(4, 64), (3, 80)])
-def test_bands_reassemble_to_the_whole_frame(po, hiplib, engine, world, size):
+def test_bands_match_oracle_and_reassemble(po, hiplib, engine, world, size):
     from radnerf.parallel import TileParallelRenderer
     from radnerf.scene import SyntheticScene, default_opt
     scene = SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine=engine))
     m = scene.model
+    om = po.model_from_module(m)
+    rc = po.render_cfg_from_module(m, scene.opt.dt_gamma, scene.opt.max_steps)
     with torch.no_grad():
         m.enc_a = None
         whole = (scene.render(0)["image"].reshape(size, size, 3) * 255).to(torch.uint8)
@@ -23,8 +29,37 @@ def test_bands_reassemble_to_the_whole_frame(po, hiplib, engine, world, size):
         for r in range(world):
             tpr = TileParallelRenderer(scene, r, world, None, band=8)
             m.enc_a = None                      # each real rank owns its model: frame 0 starts without EMA history
-            frame[tpr.rows[r].cuda()] = tpr.render_local(0)
+            band = tpr.render_local(0)
+            f, (rays_o, rays_d), (bg_coords, bg_color) = tpr._inputs(0)
+            img, _, _ = po.render_frame(om, rc, rays_o.cpu().numpy(), rays_d.cpu().numpy(), m.enc_a.cpu().numpy(),
+                                        m.individual_codes[0].detach().cpu().numpy(), f["eye"].cpu().numpy(),
+                                        bg_coords.cpu().numpy(), f["poses"].cpu().numpy(),
+                                        m.individual_codes_torso[0].detach().cpu().numpy(), bg_color.reshape(-1, 3).cpu().numpy())
+            expect = (torch.from_numpy(img).reshape(-1, size, 3) * 255).to(torch.uint8)
+            d = (band.cpu().int() - expect.int()).abs()
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-3, (r, int(d.max()))
+            frame[tpr.rows[r].cuda()] = band
             covered[tpr.rows[r]] += 1
     assert (covered == 1).all()
     diff = (frame.int() - whole.int()).abs()
-    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3      # same pixels, up to a rounding flip
+    # local (band) schedule vs whole-frame schedule: small, bounded; the frame-schedule test below closes the gap
+    assert int(diff.max()) <= 13 and float(diff.float().mean()) < 1.0, (int(diff.max()), float(diff.float().mean()))
+
+
+def test_two_ranks_with_frame_schedule_equal_the_whole_frame(hiplib):
+    """End to end, two processes (gloo, both on this box's one GPU): bands rendered with the whole-frame step
+    schedule (rn_head_reschedule + a 4-byte all-reduce per iteration) and gathered give the single-process frame."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "tile_check.py"), "--size", "96", "--frames", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "frame 2: max |d|" in r.stdout

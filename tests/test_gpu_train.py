@@ -158,21 +158,31 @@ def test_trainer_steps_reduce_the_loss(hiplib):
     (nerf/utils.py:718-806, 1003-1040; main.py:204).  Target = the scene's own frozen render, so a perturbed copy
     of the model must move back towards it."""
     from radnerf.train import SyntheticTrainStream, Trainer
-    scene = _scene(64, torso=False)
+    scene = _scene(64, torso=False, smooth_lips=False)       # --smooth_lips is a test-time flag (main.py:49)
     stream = SyntheticTrainStream(scene, n_rays=2048)
     m = scene.model
     with torch.no_grad():                       # knock the colour head off target
-        m.color_net.net[-1].weight.add_(0.3 * torch.randn_like(m.color_net.net[-1].weight))
-    trainer = Trainer(m, scene.opt, update_extra_interval=0)     # keep the ellipsoid occupancy (a3 has its own tests)
+        m.color_net.net[-1].weight.add_(0.5 * torch.randn_like(m.color_net.net[-1].weight))
+    trainer = Trainer(m, scene.opt, lr_net=5e-3, update_extra_interval=0)   # keep the ellipsoid occupancy (a3 has its own tests)
+    from radnerf.train import train_step
+    probe = stream.batch()
+
+    def mse():
+        m.train()
+        with torch.no_grad():
+            pred, rgb, _ = train_step(m, probe, scene.opt)
+        return float(((pred - rgb) ** 2).mean())
+    before = mse()
     losses = [float(trainer.step(stream.batch())) for _ in range(40)]
+    after = mse()
     assert all(np.isfinite(losses))
-    assert np.mean(losses[-5:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-5:])
-    assert int(m.step_counter[:, 0].max()) > 0 and m.local_step == 40
+    assert after < 0.5 * before, (before, after)
+    assert int(m.step_counter[:, 0].max()) > 0 and m.local_step == 42
 
 
 def test_trainer_refreshes_occupancy_every_interval(hiplib):
     from radnerf.train import SyntheticTrainStream, Trainer
-    scene = _scene(32, torso=False)
+    scene = _scene(32, torso=False, smooth_lips=False)
     stream = SyntheticTrainStream(scene, n_rays=512)
     m = scene.model
     trainer = Trainer(m, scene.opt, update_extra_interval=4)
