@@ -131,19 +131,53 @@ __device__ __forceinline__ void atomic_add_row(__half *p, const float (&v)[2]) {
     __builtin_amdgcn_global_atomic_fadd_v2f16((gptr_t)(p), x);
 }
 
+// Scatter-add with wave-level pre-reduction.  Samples arrive ray-ordered, so neighbouring lanes often hit the same
+// table row (always on the coarse levels; on every level of the ambient grid, whose coordinates cluster around 0) and
+// plain atomics then serialise on one address in L2.  Lanes with equal keys in consecutive lanes form a run; a
+// segmented inclusive scan (6 shuffle steps, the run heads taken from one ballot) sums each run and only its last lane
+// issues the atomic.  Waves with few repeats skip the scan.  `key` must be ~0u on lanes that contribute nothing.
+template <typename T, uint32_t N_C>
+__device__ __forceinline__ void scatter_add_runs(T *__restrict__ table, uint32_t key, float (&v)[N_C]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    const bool valid = key != ~0u;
+    if (__popcll(heads) > 40) {  // mostly distinct rows: the scan would not pay
+        if (valid) atomic_add_row(table + key, v);
+        return;
+    }
+    // first lane of my run: highest head bit at or below my lane
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    const uint32_t start = 63u - (uint32_t)__clzll(below);
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        float up[N_C];
+#pragma unroll
+        for (uint32_t c = 0; c < N_C; c++) up[c] = __shfl_up(v[c], off, 64);
+        if (lane >= start + off) {
+#pragma unroll
+            for (uint32_t c = 0; c < N_C; c++) v[c] += up[c];
+        }
+    }
+    const bool tail = lane == 63u || ((heads >> (lane + 1)) & 1ull);
+    if (tail && valid) atomic_add_row(table + key, v);
+}
+
 template <typename T, uint32_t D, uint32_t C, uint32_t N_C, int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_grid_bwd_table(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
                  T *__restrict__ grad_grid, uint32_t B, uint32_t L, LevelConsts lc, uint32_t gridtype,
                  bool align_corners, uint32_t interp) {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t b = tid * N_C / C;
-    if (b >= B) return;
+    const uint32_t b_raw = tid * N_C / C;
+    const bool in_range = b_raw < B;
+    const uint32_t b = in_range ? b_raw : 0u;   // lanes past the end stay in the wave (shuffles below), contributing nothing
     const uint32_t level = blockIdx.y;
-    const uint32_t ch = tid * N_C - b * C;
+    const uint32_t ch = tid * N_C - b_raw * C;
 
     float in[D];
-    if (load_input<D>(inputs, b, in)) return;  // grad table is zero-initialised (gridencoder.cu:275-280)
+    const bool live = !load_input<D>(inputs, b, in) && in_range;  // grad table is zero-initialised (gridencoder.cu:275-280)
 
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
@@ -154,14 +188,18 @@ k_grid_bwd_table(const T *__restrict__ grad, const float *__restrict__ inputs, c
     uint32_t pos_grid[D];
     lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
 
-    const T *g = (LAYOUT == RN_LAYOUT_LBC) ? grad + ((size_t)level * B + b) * C + ch : grad + ((size_t)b * L + level) * C + ch;
-    T gc[N_C];
-    load_row<T, N_C>(g, gc);
     float grad_cur[N_C];
 #pragma unroll
-    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = to_f<T>(gc[c]);
+    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = 0.0f;
+    if (live) {
+        const T *g = (LAYOUT == RN_LAYOUT_LBC) ? grad + ((size_t)level * B + b) * C + ch : grad + ((size_t)b * L + level) * C + ch;
+        T gc[N_C];
+        load_row<T, N_C>(g, gc);
+#pragma unroll
+        for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = to_f<T>(gc[c]);
+    }
 
-    T *gg = grad_grid + (size_t)off * C + ch;
+    T *gg = grad_grid + (size_t)off * C;
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         float w = 1;
@@ -172,11 +210,11 @@ k_grid_bwd_table(const T *__restrict__ grad, const float *__restrict__ inputs, c
             w *= hi ? pos[d] : 1 - pos[d];
             pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
         }
-        const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        const uint32_t row = live ? grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl) : 0u;
         float v[N_C];
 #pragma unroll
         for (uint32_t c = 0; c < N_C; c++) v[c] = w * grad_cur[c];
-        atomic_add_row(gg + (size_t)row * C, v);
+        scatter_add_runs<T, N_C>(gg, live ? row * C + ch : ~0u, v);
     }
 }
 

@@ -391,6 +391,36 @@ def test_grid_backward_fp32(po, hiplib, rng, D, C, L, log2T, gridtype, B, layout
     np.testing.assert_array_equal(n(gi), e_gi)  # sequential per (b, d): same order -> exact
 
 
+@pytest.mark.parametrize("pattern", ["clustered", "ray_runs", "ragged_tail", "with_oob"])
+@pytest.mark.parametrize("D,C", [(2, 2), (3, 2), (3, 1), (2, 4)])
+def test_grid_backward_colliding_samples(po, hiplib, rng, D, C, pattern):
+    """The scatter-add pre-reduces runs of equal rows inside a wave (ambient coordinates cluster around one cell,
+    ray-ordered samples share coarse cells): the sums must still be the reference's (gridencoder.cu:247-339)."""
+    import radnerf_hip as hip
+    from gridencoder.encoder import level_offsets
+    L, log2T, gridtype = 16, 16, 1
+    B = {"clustered": 5000, "ray_runs": 4096, "ragged_tail": 1000 + 37, "with_oob": 3000}[pattern]
+    pls = np.exp2(np.log2(2048 / 16) / (L - 1))
+    offsets = level_offsets(D, L, pls, 16, log2T, False)
+    S = float(np.log2(pls))
+    emb = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    if pattern == "clustered":
+        x = (0.5 + 1e-4 * rng.standard_normal((B, D))).astype(np.float32)
+    elif pattern == "ray_runs":
+        o = rng.uniform(0.2, 0.8, (B // 16, 1, D)); d = rng.standard_normal((B // 16, 1, D)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        x = np.clip(o + d * (0.0135 * np.arange(16))[None, :, None], 0, 1).reshape(B, D).astype(np.float32)
+    else:
+        x = np.repeat(rng.uniform(0, 1, (B // 8 + 1, D)), 8, axis=0)[:B].astype(np.float32)
+        if pattern == "with_oob":
+            x[::7] = 1.5          # skipped samples inside the runs
+    grad = rng.standard_normal((L, B, C)).astype(np.float32)
+    e_ge, _ = po.grid_encode_backward(grad, x, emb, offsets, B, D, C, L, S, 16, None, gridtype, False, 0)
+    ge = torch.zeros(emb.shape, device=DEV)
+    hip.call("rn_grid_encode_backward", dp(grad), dp(x), dp(emb), dp(offsets), hip.ptr(ge), B, D, C, L, S, 16, None, None,
+             gridtype, 0, 0, hip.RN_F32, 0, hip.stream())
+    np.testing.assert_allclose(n(ge), e_ge, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(e_ge).max()))
+
+
 def test_grid_backward_fp16(po, hiplib, rng):
     import radnerf_hip as hip
     D, C, L, log2T, gridtype, B = 3, 2, 16, 16, 1, 3000
