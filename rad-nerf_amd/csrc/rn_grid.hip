@@ -218,6 +218,72 @@ k_grid_bwd_table(const T *__restrict__ grad, const float *__restrict__ inputs, c
     }
 }
 
+// Scatter-add with block-level pre-reduction (C <= 2, D <= 3: one lane per sample and level).  The 256 samples of a
+// block touch 256 * 2^D rows of one level; ray-ordered samples share most of them on the coarse levels, and the
+// corners of neighbouring samples coincide, so the block first sums them in an LDS hash table (open addressing,
+// load factor <= 0.5, ds_cmpst + ds_add_f32) and then issues ONE global atomic per distinct row.  Device-scope
+// float atomics on this part resolve behind the per-XCD L2s, so their count -- not their bytes -- is the cost.
+template <typename T, uint32_t D, uint32_t C, int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_bwd_table_merge(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                       T *__restrict__ grad_grid, uint32_t B, uint32_t L, LevelConsts lc, uint32_t gridtype,
+                       bool align_corners, uint32_t interp) {
+    constexpr uint32_t kSlots = 256u * (1u << D) * 2u;
+    constexpr uint32_t kEmpty = 0xffffffffu;
+    __shared__ uint32_t keys[kSlots];
+    __shared__ float vals[kSlots * C];
+    for (uint32_t i = threadIdx.x; i < kSlots; i += 256) keys[i] = kEmpty;
+    for (uint32_t i = threadIdx.x; i < kSlots * C; i += 256) vals[i] = 0.0f;
+    __syncthreads();
+
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off = (uint32_t)offsets[level];
+    float in[D];
+    if (b < B && !load_input<D>(inputs, b, in)) {
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+        const float scale = lc.scale[level];
+        const uint32_t resolution = lc.resolution[level];
+        float pos[D], pos_deriv[D];
+        uint32_t pos_grid[D];
+        lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
+        const T *g = (LAYOUT == RN_LAYOUT_LBC) ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
+        T gc[C];
+        load_row<T, C>(g, gc);
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            float w = 1;
+            uint32_t pgl[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                const bool hi = (idx >> d) & 1u;
+                w *= hi ? pos[d] : 1 - pos[d];
+                pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
+            }
+            const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            uint32_t slot = (row * 2654435761u) & (kSlots - 1u);
+            while (true) {
+                const uint32_t prev = atomicCAS(&keys[slot], kEmpty, row);
+                if (prev == kEmpty || prev == row) break;
+                slot = (slot + 1u) & (kSlots - 1u);
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) atomicAdd(&vals[slot * C + c], w * to_f<T>(gc[c]));
+        }
+    }
+    __syncthreads();
+    T *gg = grad_grid + (size_t)off * C;
+    for (uint32_t i = threadIdx.x; i < kSlots; i += 256) {
+        const uint32_t row = keys[i];
+        if (row != kEmpty) {
+            float v[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) v[c] = vals[i * C + c];
+            atomic_add_row(gg + (size_t)row * C, v);
+        }
+    }
+}
+
 // Backward to the inputs (gridencoder.cu:342-368): grad_inputs[b,d] = sum_{l,ch} grad * dy_dx.
 template <typename T, uint32_t D, uint32_t C, int LAYOUT>
 __global__ void __launch_bounds__(256)
@@ -355,7 +421,14 @@ static void launch_bwd(const BwdArgs &a) {
     const T *grad = static_cast<const T *>(a.grad);
     T *gt = static_cast<T *>(a.grad_table);
     const dim3 block(256), grid(div_up(a.B * C / N_C, 256), a.L);
-    if (a.layout == RN_LAYOUT_LBC)
+    if constexpr (C <= 2 && D <= 3) {
+        if (a.layout == RN_LAYOUT_LBC)
+            hipLaunchKernelGGL((k_grid_bwd_table_merge<T, D, C, RN_LAYOUT_LBC>), grid, block, 0, a.stream, grad, a.inputs,
+                               a.offsets, gt, a.B, a.L, a.lc, a.gridtype, a.align_corners, a.interp);
+        else
+            hipLaunchKernelGGL((k_grid_bwd_table_merge<T, D, C, RN_LAYOUT_BLC>), grid, block, 0, a.stream, grad, a.inputs,
+                               a.offsets, gt, a.B, a.L, a.lc, a.gridtype, a.align_corners, a.interp);
+    } else if (a.layout == RN_LAYOUT_LBC)
         hipLaunchKernelGGL((k_grid_bwd_table<T, D, C, N_C, RN_LAYOUT_LBC>), grid, block, 0, a.stream, grad, a.inputs,
                            a.offsets, gt, a.B, a.L, a.lc, a.gridtype, a.align_corners, a.interp);
     else
