@@ -44,6 +44,9 @@ def parse():
                          "config[2], one optimisation step of 4096 rays (march_rays_train + network + "
                          "composite_rays_train, backward, Adam)")
     ap.add_argument("--rays", type=int, default=4096, help="rays per training step (--workload train)")
+    ap.add_argument("--mlp", default="f32", choices=["f32", "f16"],
+                    help="arithmetic of the fused kernel's contractions: f32 = v_mfma_f32_32x32x2_f32 (headline, fp32 parity); "
+                         "f16 = v_mfma_f32_32x32x16_f16 with fp32 accumulation (the reference's -O/autocast arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -69,6 +72,7 @@ GRID_XYZ_BYTES_PER_SAMPLE = 1024 + 12 + 128
 FUSED_BYTES_PER_SAMPLE = 1024 + 512 + 12 + 12 + 4 + 4 + 12
 MLP_FLOP_PER_SAMPLE = 56704          # 2 x 28352 MAC
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16/bf16 (v_mfma_f32_32x32x16_f16)
 
 
 def kernel_select(engine, acc):
@@ -200,7 +204,7 @@ def main():
     K, W = args.steps, args.warmup
     n_frames = 250
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
-                           opt=default_opt(engine=engine, **GRIDS[args.grid]))
+                           opt=default_opt(engine=engine, mlp_dtype=args.mlp, **GRIDS[args.grid]))
     tile = args.workload == "tile"
     fpr = (TileParallelRenderer if tile else FrameParallelRenderer)(scene, rank, world, dist)
 
@@ -253,23 +257,28 @@ def main():
             nbytes = live_total * FUSED_BYTES_PER_SAMPLE
             achieved = nbytes / (fused_ms * 1e-3) / 1e9
             tflops = live_total * MLP_FLOP_PER_SAMPLE / (fused_ms * 1e-3) / 1e12
-            # The kernel does both of the path's heavy jobs (grid gathers and the MLP contraction); of its two
-            # roofs the matrix-core one is the closer (binding) one, so that is `bound`; the HBM view rides along.
-            roof = dict(bound="mfma", kernel="k_nerf_fused (grid gathers + fp32 MFMA MLPs)", achieved=tflops,
-                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / MFMA_F32_PEAK_TFLOPS,
-                        traffic=fpr.measured_traffic("nerf_fused"), launches=fused_launches,
-                        avg_launch_ms=fused_ms / fused_launches,
-                        algorithmic_flop_per_launch=live_total * MLP_FLOP_PER_SAMPLE / fused_launches,
-                        algorithmic_flop_per_sample=MLP_FLOP_PER_SAMPLE,
-                        share_of_step=fused_ms / (elapsed * 1e3),
-                        launches_with_work=iters_total,
-                        avg_launch_ms_with_work=sum(fused_durs[:iters_total]) / max(iters_total, 1),
-                        note="launches/avg_launch_ms count every launch of the kernel (max_steps per frame, as rocprof "
-                             "does); iterations past the end of the loop launch with zero samples and exit at once; "
-                             "traffic = HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes in profiles/",
-                        hbm=dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                                 algorithmic_bytes_per_launch=nbytes / fused_launches,
-                                 algorithmic_bytes_per_sample=FUSED_BYTES_PER_SAMPLE))
+            # The kernel does both of the path's heavy jobs (grid gathers and the MLP contraction).  With fp32 MFMA the
+            # matrix-core roof is the closer (binding) one; on the 16-bit matrix cores the contraction is ~16x cheaper and
+            # the gathers bind.  `bound` names the binding roof, the other view rides along.
+            common = dict(traffic=fpr.measured_traffic("nerf_fused" if args.mlp == "f32" else "nerf_fused_h16"),
+                          launches=fused_launches, avg_launch_ms=fused_ms / fused_launches,
+                          share_of_step=fused_ms / (elapsed * 1e3), launches_with_work=iters_total,
+                          avg_launch_ms_with_work=sum(fused_durs[:iters_total]) / max(iters_total, 1),
+                          note="launches/avg_launch_ms count every launch of the kernel (max_steps per frame, as rocprof "
+                               "does); iterations past the end of the loop launch with zero samples and exit at once; "
+                               "traffic = HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes in profiles/")
+            mfma_peak = MFMA_F32_PEAK_TFLOPS if args.mlp == "f32" else MFMA_F16_PEAK_TFLOPS
+            mfma_view = dict(achieved=tflops, peak=mfma_peak, unit="TFLOP/s", frac=tflops / mfma_peak,
+                             algorithmic_flop_per_launch=live_total * MLP_FLOP_PER_SAMPLE / fused_launches,
+                             algorithmic_flop_per_sample=MLP_FLOP_PER_SAMPLE)
+            hbm_view = dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                            algorithmic_bytes_per_launch=nbytes / fused_launches,
+                            algorithmic_bytes_per_sample=FUSED_BYTES_PER_SAMPLE)
+            if args.mlp == "f32":
+                roof = dict(bound="mfma", kernel="k_nerf_fused (grid gathers + fp32 MFMA MLPs)", **mfma_view, **common, hbm=hbm_view)
+            else:
+                roof = dict(bound="hbm", kernel="k_nerf_fused_h16 (grid gathers + f16 MFMA MLPs, fp32 accumulate)", **hbm_view,
+                            **common, mfma=mfma_view)
         for key, r in res.items():
             per_launch_bytes = acc.get(key, 0.0) / max(r["launches"], 1)
             achieved = per_launch_bytes / (r["avg_ms"] * 1e-3) / 1e9 if r["avg_ms"] > 0 else 0.0
@@ -280,7 +289,8 @@ def main():
         out = {
             "metric": f"rendered frames/sec @{size}x{size}", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if tile else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.mlp == "f32" else "f16 operands / f32 accumulate",
+            "data": "synthetic",
             "config": {"workload": (f"config[4]: tile-parallel single {size}x{size} frame, interleaved 8-row bands, " if tile else
                                     f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "
                                    "max 16 steps/ray, 25 FPS pose stream, torso pass on",

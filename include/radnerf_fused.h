@@ -54,6 +54,13 @@ typedef struct {
 
 /* Number of floats of the packed (MFMA-ordered) weight image / of the per-frame bias block. */
 size_t rn_nerf_packed_floats(void);
+/* Opt-in 16-bit matrix-core variant (mlp_dtype = RN_F16 below): weights and per-sample activations are rounded to fp16
+ * where they enter v_mfma_f32_32x32x16_f16, accumulation stays fp32 -- the arithmetic of the reference's `-O`
+ * (autocast) mode, nerf/utils.py:944.  Grid interpolation, per-frame bias vectors, the narrow output layers and the
+ * activations stay fp32.  Its weight image has its own size and packer; `packed` passed to rn_nerf_fused_forward /
+ * rn_head_iterate must be the image that matches `mlp_dtype` (RN_F32: rn_nerf_pack_weights). */
+size_t rn_nerf_packed_floats_h16(void);
+int rn_nerf_pack_weights_h16(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);
 size_t rn_nerf_bias_floats(void);
 /* Re-order the raw weights into the image the fused kernel stages into LDS (call when weights change). */
 int rn_nerf_pack_weights(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);
@@ -67,7 +74,7 @@ int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const flo
 int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *deltas, uint32_t M,
                           const int32_t *m_dev, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb,
                           const float *packed, const float *bias, float bound, float *sigmas, float *rgbs,
-                          float *ambient, rn_stream_t stream);
+                          float *ambient, int mlp_dtype, rn_stream_t stream);
 
 /* ---- device-side inference loop ------------------------------------------------------------------ */
 #define RN_HEAD_STATE_INTS 32 /* int32 words of loop state the caller provides (zeroing not required) */
@@ -99,7 +106,7 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream);
 /* Enqueue loop iterations first_iter .. first_iter + n_iters - 1.  Iterations past the end of the loop
  * (step >= max_steps or no ray alive) are no-ops decided on the device. */
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
-                    const float *bias, uint32_t first_iter, uint32_t n_iters, rn_stream_t stream);
+                    const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream);
 /* Step schedule of a SHARD of a frame (tile-parallel rendering, BASELINE config 4).  The reference's policy
  * n_step = max(min(N // n_alive, 8), 1) (nerf/renderer.py:249) uses the ray count and the live count of the whole
  * call; a rank that renders only a band of the image reproduces the whole-frame schedule (and so the whole-frame

@@ -58,6 +58,42 @@ static void mlp_rows(const orc_mlp_t *mlp, const float *const *wt, const float *
     }
 }
 
+/* The same stack under the arithmetic of the opt-in 16-bit matrix-core kernel (rad-nerf_amd/csrc/rn_fused_h16.hip), which
+ * is the reference's autocast mode (nerf/utils.py:944: nn.Linear in fp16, fp32 accumulation) with fp32 kept where the
+ * kernel keeps it: inputs k < n_var of the first layer, every hidden activation and the weights that multiply them are
+ * rounded to fp16 (nearest-even); the broadcast inputs k >= n_var (audio code / eye / individual code, folded into a
+ * per-frame bias) and the first n_fp32_rows rows of the LAST layer (the narrow outputs computed on the vector ALU) use
+ * unrounded fp32 operands.  Products are exact in fp32, sums are fp32. */
+static float rh(float v) { return orc_half_to_float(orc_float_to_half(v)); }
+static void mlp_rows_mp(const orc_mlp_t *mlp, const float *const *wt, const float *x, uint32_t B,
+                        uint32_t ldx, float *out, uint32_t ldo, uint32_t n_var, uint32_t n_fp32_rows) {
+    float a[MAX_W], c[MAX_W];
+    for (uint32_t b = 0; b < B; b++) {
+        uint32_t din = mlp->dim_in;
+        memcpy(a, x + (size_t)b * ldx, din * sizeof(float));
+        for (uint32_t l = 0; l < mlp->num_layers; l++) {
+            const int last = l == mlp->num_layers - 1;
+            const uint32_t dout = last ? mlp->dim_out : mlp->dim_hidden;
+            const float *w = wt[l]; /* transposed copy: [din][dout] */
+            for (uint32_t o = 0; o < dout; o++) c[o] = 0.0f;
+            for (uint32_t k = 0; k < din; k++) {
+                const int wide_in = (l == 0 && k >= n_var);
+                const float xk = a[k], xh = rh(a[k]);
+                const float *wk = w + (size_t)k * dout;
+                for (uint32_t o = 0; o < dout; o++) {
+                    const int wide = wide_in || (last && l > 0 && o < n_fp32_rows);
+                    c[o] += wide ? xk * wk[o] : xh * rh(wk[o]);
+                }
+            }
+            if (!last)
+                for (uint32_t o = 0; o < dout; o++) c[o] = c[o] > 0.0f ? c[o] : 0.0f;
+            memcpy(a, c, dout * sizeof(float));
+            din = dout;
+        }
+        memcpy(out + (size_t)b * ldo, a, mlp->dim_out * sizeof(float));
+    }
+}
+
 static void mlp_transpose(const orc_mlp_t *mlp, float **wt) {
     uint32_t din = mlp->dim_in;
     for (uint32_t l = 0; l < mlp->num_layers; l++) {
@@ -107,7 +143,7 @@ typedef struct {
 static void nerf_chunk(const orc_model_t *m, const nerf_wt_t *wt, const float *xyzs,
                        const float *dirs, uint32_t n, const float *enc_a, const float *ind_code,
                        const float *eye, float *sigma, float *color, float *ambient,
-                       int density_only) {
+                       int density_only, int mp) {
     const uint32_t gx = m->enc_xyz.L * m->enc_xyz.C, gw = m->enc_ambient.L * m->enc_ambient.C;
     const uint32_t A = m->audio_dim;
     const uint32_t in_amb = gx + A, in_sig = gx + gw + (m->has_eye ? 1u : 0u);
@@ -130,7 +166,8 @@ static void nerf_chunk(const orc_model_t *m, const nerf_wt_t *wt, const float *x
         memcpy(h + (size_t)b * in_amb, encx + (size_t)b * gx, gx * sizeof(float));
         memcpy(h + (size_t)b * in_amb + gx, enc_a, A * sizeof(float));
     }
-    mlp_rows(&m->ambient_net, (const float *const *)wt->wa, h, n, in_amb, amb, 2);
+    if (mp) mlp_rows_mp(&m->ambient_net, (const float *const *)wt->wa, h, n, in_amb, amb, 2, gx, 2);
+    else mlp_rows(&m->ambient_net, (const float *const *)wt->wa, h, n, in_amb, amb, 2);
     for (uint32_t i = 0; i < n * 2; i++) amb[i] = tanhf(amb[i]);
     if (ambient) memcpy(ambient, amb, (size_t)n * 2 * sizeof(float));
 
@@ -146,7 +183,8 @@ static void nerf_chunk(const orc_model_t *m, const nerf_wt_t *wt, const float *x
         memcpy(row + gx, encw_perm + (size_t)b * gw, gw * sizeof(float));
         if (m->has_eye) row[gx + gw] = eye[0];
     }
-    mlp_rows(&m->sigma_net, (const float *const *)wt->ws, h, n, in_sig, sg, m->sigma_net.dim_out);
+    if (mp) mlp_rows_mp(&m->sigma_net, (const float *const *)wt->ws, h, n, in_sig, sg, m->sigma_net.dim_out, gx + gw, 1);
+    else mlp_rows(&m->sigma_net, (const float *const *)wt->ws, h, n, in_sig, sg, m->sigma_net.dim_out);
 
     /* sigma = trunc_exp(h[..., 0])  :264, activation.py:5-11 */
     for (uint32_t b = 0; b < n; b++) sigma[b] = expf(sg[(size_t)b * m->sigma_net.dim_out]);
@@ -161,7 +199,8 @@ static void nerf_chunk(const orc_model_t *m, const nerf_wt_t *wt, const float *x
             memcpy(row + nsh, sg + (size_t)b * m->sigma_net.dim_out + 1, geo * sizeof(float));
             if (m->ind_dim) memcpy(row + nsh + geo, ind_code, m->ind_dim * sizeof(float));
         }
-        mlp_rows(&m->color_net, (const float *const *)wt->wc, h, n, in_col, color, 3);
+        if (mp) mlp_rows_mp(&m->color_net, (const float *const *)wt->wc, h, n, in_col, color, 3, nsh + geo, 3);
+        else mlp_rows(&m->color_net, (const float *const *)wt->wc, h, n, in_col, color, 3);
         for (uint32_t i = 0; i < n * 3; i++) color[i] = 1.0f / (1.0f + expf(-color[i]));
     }
     free(tin); free(tout); free(h); free(amb); free(sg); free(encx); free(encw_perm);
@@ -169,7 +208,7 @@ static void nerf_chunk(const orc_model_t *m, const nerf_wt_t *wt, const float *x
 
 static void nerf_run(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
                      const float *enc_a, const float *ind_code, const float *eye, float *sigma,
-                     float *color, float *ambient, int density_only) {
+                     float *color, float *ambient, int density_only, int mp) {
     nerf_wt_t wt;
     mlp_transpose(&m->ambient_net, wt.wa);
     mlp_transpose(&m->sigma_net, wt.ws);
@@ -179,7 +218,7 @@ static void nerf_run(const orc_model_t *m, const float *xyzs, const float *dirs,
         const uint32_t n = (uint32_t)((int64_t)M - c0 < CHUNK ? (int64_t)M - c0 : CHUNK);
         nerf_chunk(m, &wt, xyzs + (size_t)c0 * 3, dirs ? dirs + (size_t)c0 * 3 : NULL, n, enc_a,
                    ind_code, eye, sigma + c0, color ? color + (size_t)c0 * 3 : NULL,
-                   ambient ? ambient + (size_t)c0 * 2 : NULL, density_only);
+                   ambient ? ambient + (size_t)c0 * 2 : NULL, density_only, mp);
     }
     mlp_free(&m->ambient_net, wt.wa);
     mlp_free(&m->sigma_net, wt.ws);
@@ -189,12 +228,18 @@ static void nerf_run(const orc_model_t *m, const float *xyzs, const float *dirs,
 void orc_nerf_forward(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
                       const float *enc_a, const float *ind_code, const float *eye,
                       float *sigma, float *color, float *ambient) {
-    nerf_run(m, xyzs, dirs, M, enc_a, ind_code, eye, sigma, color, ambient, 0);
+    nerf_run(m, xyzs, dirs, M, enc_a, ind_code, eye, sigma, color, ambient, 0, 0);
+}
+
+void orc_nerf_forward_mp16(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
+                           const float *enc_a, const float *ind_code, const float *eye,
+                           float *sigma, float *color, float *ambient) {
+    nerf_run(m, xyzs, dirs, M, enc_a, ind_code, eye, sigma, color, ambient, 0, 1);
 }
 
 void orc_nerf_density(const orc_model_t *m, const float *xyzs, uint32_t M, const float *enc_a,
                       const float *eye, float *sigma) {
-    nerf_run(m, xyzs, NULL, M, enc_a, NULL, eye, sigma, NULL, NULL, 1);
+    nerf_run(m, xyzs, NULL, M, enc_a, NULL, eye, sigma, NULL, NULL, 1, 0);
 }
 
 /* nerf/network.py:188-219 */

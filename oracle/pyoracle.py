@@ -402,13 +402,14 @@ def mlp_forward(weights, x):
     return out
 
 
-def nerf_forward(model, xyzs, dirs, enc_a, ind_code, eye):
+def nerf_forward(model, xyzs, dirs, enc_a, ind_code, eye, mlp_dtype="f32"):
+    """mlp_dtype="f16": the arithmetic of the opt-in 16-bit matrix-core kernel (orc_nerf_forward_mp16)."""
     xyzs, dirs = _f32(xyzs), _f32(dirs)
     enc_a, ind_code, eye = _f32(enc_a).reshape(-1), _f32(ind_code).reshape(-1), _f32(eye).reshape(-1)
     M = xyzs.shape[0]
     sigma, color, amb = np.empty(M, np.float32), np.empty((M, 3), np.float32), np.empty((M, 2), np.float32)
-    lib().orc_nerf_forward(C.byref(model.c), _p(xyzs), _p(dirs), u32(M), _p(enc_a), _p(ind_code), _p(eye),
-                           _p(sigma), _p(color), _p(amb))
+    fn = lib().orc_nerf_forward_mp16 if mlp_dtype == "f16" else lib().orc_nerf_forward
+    fn(C.byref(model.c), _p(xyzs), _p(dirs), u32(M), _p(enc_a), _p(ind_code), _p(eye), _p(sigma), _p(color), _p(amb))
     return sigma, color, amb
 
 

@@ -172,6 +172,11 @@ void orc_mlp_forward(const orc_mlp_t *mlp, const float *x, uint32_t B, float *ou
 void orc_nerf_forward(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
                       const float *enc_a, const float *ind_code, const float *eye,
                       float *sigma, float *color, float *ambient);
+/* The same forward under the arithmetic of the opt-in 16-bit matrix-core kernel (fp16 operands where they enter a
+ * matrix instruction, fp32 accumulation; see mlp_rows_mp in orc_nerf.c) -- the checker for mlp_dtype = RN_F16. */
+void orc_nerf_forward_mp16(const orc_model_t *m, const float *xyzs, const float *dirs, uint32_t M,
+                           const float *enc_a, const float *ind_code, const float *eye,
+                           float *sigma, float *color, float *ambient);
 /* NeRFNetwork.density (nerf/network.py:286-325): sigma only. */
 void orc_nerf_density(const orc_model_t *m, const float *xyzs, uint32_t M, const float *enc_a,
                       const float *eye, float *sigma);

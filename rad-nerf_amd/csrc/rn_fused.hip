@@ -20,20 +20,11 @@
 //    the accumulator registers + one cross-half shuffle.
 //  * the inference loop keeps n_alive / step / n_step in device memory (double-buffered state words), so
 //    a frame is enqueued without a single host read-back; compaction is a stable ballot/mbcnt scatter.
-#include "rn_dda_dev.h"
-#include "rn_grid_dev.h"
-#include "rn_sh_dev.h"
-
-#include "../../include/radnerf_fused.h"
+#include "rn_fused_dev.h"
 
 #include <float.h>
 
 namespace rn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kFusedThreads = 512;
-constexpr int kWavesPerBlock = kFusedThreads / kWave;
 
 // ---- packed weight image (floats) --------------------------------------------------------------------
 // MFMA layers: [step][h][col j][row tile] -> lane (j, h) reads one float2 per step.
@@ -50,16 +41,6 @@ constexpr int OFF_C1 = OFF_C0 + 40 * kStep;          // color L1 (VALU)       : 
 constexpr int kPacked = OFF_C1 + 192;                // 23936 floats
 constexpr int kBias = 192;                           // amb | sig | col, 64 each
 constexpr int kLdsFloats = kPacked + kBias;          // 96512 B of LDS
-
-__host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-// k index (within a 64-wide hidden vector) that lane-half h feeds at MFMA step s when the B operand is
-// register (s & 15) of row tile (s >> 4) of the previous layer's accumulators.
-__host__ __device__ constexpr int kmap(int s, int h) { return 32 * (s >> 4) + rowmap(s & 15, h); }
-
-struct RawW {
-    const float *amb_w0, *amb_w1, *amb_w2, *sig_w0, *sig_w1, *sig_w2, *col_w0, *col_w1;
-    uint32_t audio_dim, has_eye, ind_dim;
-};
 
 __global__ void __launch_bounds__(256) k_pack_nerf(RawW w, float *__restrict__ packed) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -115,41 +96,6 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc[column tile][row tile]
-struct Acc {
-    f32x16 v[2][2];
-};
-
-__device__ __forceinline__ void acc_zero(Acc &a) {
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = 0.0f;
-}
-
-// accumulator rows of lane half h: 32 rt + (r & 3) + 8 (r >> 2) + 4 h -> four consecutive floats per r >> 2
-__device__ __forceinline__ void acc_bias(Acc &a, const float *bias64, int h) {
-#pragma unroll
-    for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias64 + 32 * rt + 8 * g + 4 * h);
-            a.v[0][rt][4 * g + 0] = b.x; a.v[0][rt][4 * g + 1] = b.y; a.v[0][rt][4 * g + 2] = b.z; a.v[0][rt][4 * g + 3] = b.w;
-            a.v[1][rt][4 * g + 0] = b.x; a.v[1][rt][4 * g + 1] = b.y; a.v[1][rt][4 * g + 2] = b.z; a.v[1][rt][4 * g + 3] = b.w;
-        }
-}
-
-__device__ __forceinline__ void acc_relu(Acc &a) {
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = fmaxf(a.v[nt][rt][r], 0.0f);
-}
-
 // one MFMA step of a 64-row layer: weights of step s from LDS, B operands b0 / b1 for the two column tiles
 __device__ __forceinline__ void step64(Acc &a, const float *wl, int s, int lane_off, float b0, float b1) {
     const float2 w = *reinterpret_cast<const float2 *>(wl + s * kStep + lane_off);
@@ -165,57 +111,12 @@ __device__ __forceinline__ void layer_from_acc(Acc &out, const Acc &in, const fl
     for (int s = 0; s < 32; s++) step64(out, wl, s, lane_off, in.v[0][s >> 4][s & 15], in.v[1][s >> 4][s & 15]);
 }
 
-// out[o] (both column tiles) = sum_k in[k] * W[o][k] with the k's this lane holds; caller adds the other half
-template <int NOUT>
-__device__ __forceinline__ void valu_out(const Acc &in, const float *wl, int h, float (&part)[2][NOUT]) {
-#pragma unroll
-    for (int o = 0; o < NOUT; o++) {
-        float p0 = 0.0f, p1 = 0.0f;
-        const float *wo = wl + (o * 2 + h) * 32;
-#pragma unroll
-        for (int g = 0; g < 8; g++) {
-            const float4 w = *reinterpret_cast<const float4 *>(wo + 4 * g);
-            const int rt = g >> 2, r = (g & 3) * 4;
-            p0 = __builtin_fmaf(in.v[0][rt][r + 0], w.x, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 0], w.x, p1);
-            p0 = __builtin_fmaf(in.v[0][rt][r + 1], w.y, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 1], w.y, p1);
-            p0 = __builtin_fmaf(in.v[0][rt][r + 2], w.z, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 2], w.z, p1);
-            p0 = __builtin_fmaf(in.v[0][rt][r + 3], w.w, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 3], w.w, p1);
-        }
-        part[0][o] = p0 + __shfl_xor(p0, 32, 64);
-        part[1][o] = p1 + __shfl_xor(p1, 32, 64);
-    }
-}
-
 // "one sample per lane" feature pair (f0, f1) -> B operands of column tile 0 and 1
 __device__ __forceinline__ void to_b_operands(float f0, float f1, float &b0, float &b1) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(f0), __float_as_uint(f1), false, false);
     b0 = __uint_as_float(r[0]);
     b1 = __uint_as_float(r[1]);
 }
-
-struct GridArgs {
-    const void *table;
-    const int32_t *offsets;
-    LevelConsts lc;
-    uint32_t gridtype;
-};
-
-struct FusedParams {
-    const float *xyzs, *dirs, *deltas;
-    uint32_t M;
-    const int32_t *m_dev;
-    GridArgs gx, gw;
-    const float *packed, *bias;
-    float bound;
-    float *sigmas, *rgbs, *ambient;
-};
-
-// Per-level constants staged in LDS so that the level loops can stay rolled (a by-value kernel argument
-// indexed at run time would be copied to scratch).
-struct LevelLds {
-    float scale;
-    uint32_t resolution, offset, rows;
-};
 
 // Features (2 channels) of one sample at one level; zeros when `on` is false.
 template <typename TT, uint32_t D>
@@ -920,11 +821,15 @@ static void launch_fused(const FusedParams &p, hipStream_t s) {
 
 static int run_fused(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
                      const rn_grid_t *gx, const rn_grid_t *gw, const float *packed, const float *bias, float bound,
-                     float *sigmas, float *rgbs, float *ambient, hipStream_t s) {
+                     float *sigmas, float *rgbs, float *ambient, int mlp_dtype, hipStream_t s) {
     FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient};
     const bool prof = prof_enabled();
     if (prof) prof_begin(s);
-    if (gx->dtype == RN_F32 && gw->dtype == RN_F32) launch_fused<float, float>(p, s);
+    if (mlp_dtype == RN_F16) {
+        uint32_t blocks = div_up((M + 63u) >> 6, kWavesPerBlock);
+        const uint32_t cap = (uint32_t)num_cus();
+        launch_fused_h16(p, gx->dtype, gw->dtype, blocks > cap ? cap : blocks, s);
+    } else if (gx->dtype == RN_F32 && gw->dtype == RN_F32) launch_fused<float, float>(p, s);
     else if (gx->dtype == RN_F16 && gw->dtype == RN_F16) launch_fused<__half, __half>(p, s);
     else if (gx->dtype == RN_F32) launch_fused<float, __half>(p, s);
     else launch_fused<__half, float>(p, s);
@@ -939,6 +844,14 @@ using namespace rn;
 extern "C" {
 
 size_t rn_nerf_packed_floats(void) { return (size_t)kPacked; }
+size_t rn_nerf_packed_floats_h16(void) { return packed_floats_h16(); }
+
+int rn_nerf_pack_weights_h16(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(packed && ((uintptr_t)packed & 15u) == 0, "nerf_pack_weights_h16: packed must be 16-byte aligned");
+    launch_pack_nerf_h16(raw_w(w), packed, as_stream(stream));
+    return check_launch("nerf_pack_weights_h16");
+}
 size_t rn_nerf_bias_floats(void) { return (size_t)kBias; }
 
 int rn_nerf_pack_weights(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream) {
@@ -961,13 +874,15 @@ int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const flo
 
 int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
                           const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed, const float *bias,
-                          float bound, float *sigmas, float *rgbs, float *ambient, rn_stream_t stream) {
+                          float bound, float *sigmas, float *rgbs, float *ambient, int mlp_dtype, rn_stream_t stream) {
     if (M == 0) return RN_OK;
     RN_REQUIRE(xyzs && dirs && packed && bias && sigmas && rgbs, "nerf_fused_forward: null pointer");
     RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "nerf_fused_forward: packed must be 16-byte aligned");
     if (int rc = check_grid(grid_xyz, 3, "nerf_fused_forward(xyz grid)")) return rc;
     if (int rc = check_grid(grid_amb, 2, "nerf_fused_forward(ambient grid)")) return rc;
-    run_fused(xyzs, dirs, deltas, M, m_dev, grid_xyz, grid_amb, packed, bias, bound, sigmas, rgbs, ambient, as_stream(stream));
+    RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16, "nerf_fused_forward: mlp_dtype must be RN_F32 or RN_F16");
+    run_fused(xyzs, dirs, deltas, M, m_dev, grid_xyz, grid_amb, packed, bias, bound, sigmas, rgbs, ambient, mlp_dtype,
+              as_stream(stream));
     return check_launch("nerf_fused_forward");
 }
 
@@ -990,8 +905,9 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream) {
 }
 
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
-                    const float *bias, uint32_t first_iter, uint32_t n_iters, rn_stream_t stream) {
+                    const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream) {
     if (int rc = check_head(h)) return rc;
+    RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16, "head_iterate: mlp_dtype must be RN_F32 or RN_F16");
     RN_REQUIRE(packed && bias && ((uintptr_t)packed & 15u) == 0, "head_iterate: packed/bias");
     if (int rc = check_grid(grid_xyz, 3, "head_iterate(xyz grid)")) return rc;
     if (int rc = check_grid(grid_amb, 2, "head_iterate(ambient grid)")) return rc;
@@ -1005,7 +921,7 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
                            h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
                            h->deltas, h->state);
         run_fused(h->xyzs, h->dirs, h->deltas, h->N, st + 3, grid_xyz, grid_amb, packed, bias, h->bound, h->sigmas, h->rgbs,
-                  nullptr, s);
+                  nullptr, mlp_dtype, s);
         hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
                            h->deltas, h->weights_sum, h->depth, h->image, h->block_counts);
         hipLaunchKernelGGL(k_head_compact, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,

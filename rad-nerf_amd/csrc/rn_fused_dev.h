@@ -1,0 +1,118 @@
+// rn_fused_dev.h -- pieces shared by the fp32-MFMA (rn_fused.hip) and the f16-MFMA (rn_fused_h16.hip) variants of
+// the fused per-sample network kernel: accumulator tiles, the VALU output layers, kernel parameter blocks.
+#pragma once
+
+#include "rn_dda_dev.h"
+#include "rn_grid_dev.h"
+#include "rn_sh_dev.h"
+
+#include "../../include/radnerf_fused.h"
+
+namespace rn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFusedThreads = 512;
+constexpr int kWavesPerBlock = kFusedThreads / kWave;
+
+
+__host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// k index (within a 64-wide hidden vector) that lane-half h feeds at MFMA step s when the B operand is
+// register (s & 15) of row tile (s >> 4) of the previous layer's accumulators.
+__host__ __device__ constexpr int kmap(int s, int h) { return 32 * (s >> 4) + rowmap(s & 15, h); }
+
+struct RawW {
+    const float *amb_w0, *amb_w1, *amb_w2, *sig_w0, *sig_w1, *sig_w2, *col_w0, *col_w1;
+    uint32_t audio_dim, has_eye, ind_dim;
+};
+
+
+// acc[column tile][row tile]
+struct Acc {
+    f32x16 v[2][2];
+};
+
+__device__ __forceinline__ void acc_zero(Acc &a) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = 0.0f;
+}
+
+// accumulator rows of lane half h: 32 rt + (r & 3) + 8 (r >> 2) + 4 h -> four consecutive floats per r >> 2
+__device__ __forceinline__ void acc_bias(Acc &a, const float *bias64, int h) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias64 + 32 * rt + 8 * g + 4 * h);
+            a.v[0][rt][4 * g + 0] = b.x; a.v[0][rt][4 * g + 1] = b.y; a.v[0][rt][4 * g + 2] = b.z; a.v[0][rt][4 * g + 3] = b.w;
+            a.v[1][rt][4 * g + 0] = b.x; a.v[1][rt][4 * g + 1] = b.y; a.v[1][rt][4 * g + 2] = b.z; a.v[1][rt][4 * g + 3] = b.w;
+        }
+}
+
+__device__ __forceinline__ void acc_relu(Acc &a) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = fmaxf(a.v[nt][rt][r], 0.0f);
+}
+
+
+// out[o] (both column tiles) = sum_k in[k] * W[o][k] with the k's this lane holds; caller adds the other half
+template <int NOUT>
+__device__ __forceinline__ void valu_out(const Acc &in, const float *wl, int h, float (&part)[2][NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) {
+        float p0 = 0.0f, p1 = 0.0f;
+        const float *wo = wl + (o * 2 + h) * 32;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const float4 w = *reinterpret_cast<const float4 *>(wo + 4 * g);
+            const int rt = g >> 2, r = (g & 3) * 4;
+            p0 = __builtin_fmaf(in.v[0][rt][r + 0], w.x, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 0], w.x, p1);
+            p0 = __builtin_fmaf(in.v[0][rt][r + 1], w.y, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 1], w.y, p1);
+            p0 = __builtin_fmaf(in.v[0][rt][r + 2], w.z, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 2], w.z, p1);
+            p0 = __builtin_fmaf(in.v[0][rt][r + 3], w.w, p0); p1 = __builtin_fmaf(in.v[1][rt][r + 3], w.w, p1);
+        }
+        part[0][o] = p0 + __shfl_xor(p0, 32, 64);
+        part[1][o] = p1 + __shfl_xor(p1, 32, 64);
+    }
+}
+
+
+struct GridArgs {
+    const void *table;
+    const int32_t *offsets;
+    LevelConsts lc;
+    uint32_t gridtype;
+};
+
+struct FusedParams {
+    const float *xyzs, *dirs, *deltas;
+    uint32_t M;
+    const int32_t *m_dev;
+    GridArgs gx, gw;
+    const float *packed, *bias;
+    float bound;
+    float *sigmas, *rgbs, *ambient;
+};
+
+// Per-level constants staged in LDS so that the level loops can stay rolled (a by-value kernel argument
+// indexed at run time would be copied to scratch).
+struct LevelLds {
+    float scale;
+    uint32_t resolution, offset, rows;
+};
+
+
+// Launch of the f16-MFMA variant (rn_fused_h16.hip); `gx_dtype` / `gw_dtype` are the grid table dtypes.
+void launch_fused_h16(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t blocks, hipStream_t s);
+void launch_pack_nerf_h16(const RawW &w, float *packed, hipStream_t s);
+size_t packed_floats_h16();
+
+}  // namespace rn

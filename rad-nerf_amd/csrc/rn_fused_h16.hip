@@ -1,0 +1,343 @@
+// rn_fused_h16.hip -- the fused per-sample network kernel on the 16-bit matrix cores (opt-in, mlp_dtype = RN_F16).
+//
+// Same computation as k_nerf_fused (nerf/network.py:222-283), same tile ownership (one wavefront = 64 samples, the
+// accumulators of one layer are the B operand of the next), but the contractions run on
+// v_mfma_f32_32x32x16_f16: weights and per-sample activations are rounded to fp16 (round-to-nearest-even) where they
+// enter a matrix instruction, products are exact and accumulation is fp32.  This is the arithmetic of the reference's
+// own `-O` mode (torch.cuda.amp.autocast: nn.Linear in fp16 with fp32 accumulation, nerf/utils.py:944) except that
+// here the hidden activations stay fp32 between layers.  What stays fp32 end to end: the grid interpolation, the
+// per-frame bias vectors (audio code / eye / individual code folded once per frame), the narrow output layers
+// (ambient 2, sigma 1, rgb 3: VALU dot products over the fp32 accumulators), tanh / exp / sigmoid.
+//
+// With the contraction ~16x cheaper than on the fp32 MFMA path the kernel is gather-bound, so it is organised around
+// the gathers: no accumulator is live while grid rows are in flight, several levels are fetched at once
+// (kXyzGroup / kAmbGroup), and the feature pairs are staged through a wave-private LDS tile from which the B fragments
+// (8 consecutive k per lane half) are read back with one ds_read_b128 -- no cross-lane shuffles at all.
+#include "rn_fused_dev.h"
+
+namespace rn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- packed weight image ----------------------------------------------------------------------------------
+// MFMA section, fp16: [k-step][row tile][lane half h][row i][8 k] -> lane (i, h) reads 16 B per row tile and k-step.
+constexpr int kHStep = 2 * 2 * 32 * 8;        // halves per k-step (both row tiles)
+constexpr int KS_A0 = 0;                      // ambient L0, enc_x        : 2 k-steps
+constexpr int KS_A1 = KS_A0 + 2;              // ambient L1               : 4
+constexpr int KS_S0 = KS_A1 + 4;              // sigma L0, enc_x | enc_w  : 2 + 2
+constexpr int KS_S1 = KS_S0 + 4;              // sigma L1                 : 4
+constexpr int KS_S2 = KS_S1 + 4;              // sigma L2 rows 1..64      : 4
+constexpr int KS_C0 = KS_S2 + 4;              // color L0, sh | geo       : 1 + 4
+constexpr int kHSteps = KS_C0 + 5;            // 23
+constexpr int kHMfmaFloats = kHSteps * kHStep / 2;   // the fp16 section, counted in 4-byte units
+// VALU section, fp32 (same [out][h][q] layout as the fp32 kernel): ambient L2 | sigma L2 row 0 | color L1
+constexpr int HOFF_A2 = kHMfmaFloats;
+constexpr int HOFF_S2R = HOFF_A2 + 128;
+constexpr int HOFF_C1 = HOFF_S2R + 64;
+constexpr int kHPacked = HOFF_C1 + 192;       // 12160 four-byte units = 48.6 KB
+constexpr int kHBias = 192;
+constexpr int kStageRow = 36;                 // words per sample in the staging tile: enc_x 16 | enc_w 16 | pad (144-B rows
+                                              // keep the ds_read_b128 fragment reads conflict-free)
+constexpr int kStageWords = 64 * kStageRow;   // per wave
+
+// k index that element j of lane half h feeds at k-step (2 rt + g) when the B fragment is registers 8g..8g+7 of row
+// tile rt of the previous layer's accumulators
+__host__ __device__ constexpr int hmap(int rt, int g, int h, int j) { return 32 * rt + 16 * g + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+__global__ void __launch_bounds__(256) k_pack_nerf_h16(RawW w, float *__restrict__ packed) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int ldA0 = 32 + (int)w.audio_dim, ldS0 = 64 + (int)w.has_eye, ldC0 = 80 + (int)w.ind_dim;
+    if (e < kHSteps * kHStep) {  // one fp16 element
+        const int ks = e / kHStep, rem = e % kHStep;
+        const int rt_out = rem / 512, h = (rem % 512) / 256, i = (rem % 256) / 8, j = rem % 8;
+        const int row = 32 * rt_out + i;
+        const int nat = 8 * h + j;  // natural k inside a k-step
+        float v;
+        if (ks < KS_A1) v = w.amb_w0[row * ldA0 + 16 * (ks - KS_A0) + nat];
+        else if (ks < KS_S0) { const int q = ks - KS_A1; v = w.amb_w1[row * 64 + hmap(q >> 1, q & 1, h, j)]; }
+        else if (ks < KS_S1) v = w.sig_w0[row * ldS0 + 16 * (ks - KS_S0) + nat];
+        else if (ks < KS_S2) { const int q = ks - KS_S1; v = w.sig_w1[row * 64 + hmap(q >> 1, q & 1, h, j)]; }
+        else if (ks < KS_C0) { const int q = ks - KS_S2; v = w.sig_w2[(1 + row) * 64 + hmap(q >> 1, q & 1, h, j)]; }
+        else if (ks == KS_C0) v = w.col_w0[row * ldC0 + nat];
+        else { const int q = ks - KS_C0 - 1; v = w.col_w0[row * ldC0 + 16 + hmap(q >> 1, q & 1, h, j)]; }
+        reinterpret_cast<_Float16 *>(packed)[e] = (_Float16)v;
+        return;
+    }
+    const int f = e - kHSteps * kHStep + kHMfmaFloats;  // fp32 section
+    if (f >= kHPacked) return;
+    auto valu_elem = [&](int base, const float *src) -> float {  // [out][h][q], q = rt*16 + r
+        const int q0 = f - base, o = q0 / 64, h = (q0 % 64) / 32, q = q0 % 32;
+        return src[o * 64 + 32 * (q >> 4) + rowmap(q & 15, h)];
+    };
+    float v;
+    if (f < HOFF_S2R) v = valu_elem(HOFF_A2, w.amb_w2);
+    else if (f < HOFF_C1) v = valu_elem(HOFF_S2R, w.sig_w2);
+    else v = valu_elem(HOFF_C1, w.col_w1);
+    packed[f] = v;
+}
+
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// one k-step (16 k) of a 64-row layer: both row tiles' weight fragments from LDS, B fragments of the two column tiles
+__device__ __forceinline__ void hstep(Acc &a, const _Float16 *wl, int ks, int lane_off8, f16x8 b0, f16x8 b1) {
+    const f16x8 w0 = *reinterpret_cast<const f16x8 *>(wl + ks * kHStep + lane_off8);
+    const f16x8 w1 = *reinterpret_cast<const f16x8 *>(wl + ks * kHStep + 512 + lane_off8);
+    a.v[0][0] = mfma16(w0, b0, a.v[0][0]);
+    a.v[1][0] = mfma16(w0, b1, a.v[1][0]);
+    a.v[0][1] = mfma16(w1, b0, a.v[0][1]);
+    a.v[1][1] = mfma16(w1, b1, a.v[1][1]);
+}
+
+// registers 8g..8g+7 of one accumulator tile, rounded to fp16: the B fragment of k-step (2 rt + g) of the next layer
+__device__ __forceinline__ f16x8 acc_frag(const Acc &in, int nt, int rt, int g) {
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = (_Float16)in.v[nt][rt][8 * g + j];
+    return r;
+}
+
+__device__ __forceinline__ void hlayer_from_acc(Acc &out, const Acc &in, const _Float16 *wl, int ks0, int lane_off8) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+            hstep(out, wl, ks0 + 2 * rt + g, lane_off8, acc_frag(in, 0, rt, g), acc_frag(in, 1, rt, g));
+}
+
+__device__ __forceinline__ uint32_t pack_h2(float f0, float f1) {
+    f16x2 v;
+    v[0] = (_Float16)f0;
+    v[1] = (_Float16)f1;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// B fragments of k-step s (features 16 s .. 16 s + 15 of the staging tile) for both column tiles
+__device__ __forceinline__ void stage_frags(const uint32_t *stage, int s, int j, int h, f16x8 &b0, f16x8 &b1) {
+    const u32x4 w0 = *reinterpret_cast<const u32x4 *>(stage + j * kStageRow + 8 * s + 4 * h);
+    const u32x4 w1 = *reinterpret_cast<const u32x4 *>(stage + (32 + j) * kStageRow + 8 * s + 4 * h);
+    b0 = __builtin_bit_cast(f16x8, w0);
+    b1 = __builtin_bit_cast(f16x8, w1);
+}
+
+// all lanes of the wave have written their staging rows; make them visible to the wave's reads (wave-private tile)
+__device__ __forceinline__ void stage_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef RN_XYZ_GROUP
+#define RN_XYZ_GROUP 2
+#endif
+#ifndef RN_AMB_GROUP
+#define RN_AMB_GROUP 4
+#endif
+constexpr int kXyzGroup = RN_XYZ_GROUP;  // xyz levels fetched together (each: 16 row words + 4 in flight)
+constexpr int kAmbGroup = RN_AMB_GROUP;  // ambient-grid levels fetched together (each: 8 row words + 3)
+
+template <typename TX, typename TW>
+__global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kHPacked + kHBias];
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[kWavesPerBlock * kStageWords];
+    __shared__ LevelLds lvl_x[16], lvl_w[16];
+
+    uint32_t M = p.M;
+    if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
+    const uint32_t n_tiles = (M + 63u) >> 6;
+    if (blockIdx.x * kWavesPerBlock >= n_tiles) return;  // nothing for this workgroup (uniform)
+
+    for (int i = threadIdx.x; i < kHPacked / 4; i += kFusedThreads)
+        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
+    if (threadIdx.x < kHBias) lds[kHPacked + threadIdx.x] = p.bias[threadIdx.x];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        const uint32_t ox = (uint32_t)p.gx.offsets[t], ow = (uint32_t)p.gw.offsets[t];
+        lvl_x[t] = LevelLds{p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox};
+        lvl_w[t] = LevelLds{p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow};
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int lane_off8 = (h * 32 + j) * 8;
+    const _Float16 *wl = reinterpret_cast<const _Float16 *>(lds);
+    const float *bias_amb = lds + kHPacked, *bias_sig = lds + kHPacked + 64, *bias_col = lds + kHPacked + 128;
+    uint32_t *stage = stage_all + wave * kStageWords;
+
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+        const uint32_t sample = tile * 64 + lane;
+        bool live = sample < M;
+        if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;
+        if (__ballot(live) == 0ull) continue;  // whole tile dead (wave-uniform)
+
+        // ---- xyz grid, one sample per lane -> 16 fp16 feature pairs in the staging tile
+        {
+            float in[3] = {0.0f, 0.0f, 0.0f};
+            bool on = live;
+            if (live) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    in[d] = (p.xyzs[3 * (size_t)sample + d] + p.bound) / (2 * p.bound);
+                    on = on && !(in[d] < 0 || in[d] > 1);
+                }
+            }
+            LevelFetch<TX, 3, 2> f[kXyzGroup];
+#pragma unroll 1
+            for (int g = 0; g < 16; g += kXyzGroup) {
+                if (on) {
+#pragma unroll
+                    for (int i = 0; i < kXyzGroup; i++) {
+                        const LevelLds lv = lvl_x[g + i];
+                        issue_level<TX, 3, 2>(static_cast<const TX *>(p.gx.table) + (size_t)lv.offset * 2, in, lv.scale,
+                                              lv.resolution, lv.rows, p.gx.gridtype, false, 0, f[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kXyzGroup; i++) {
+                    uint32_t pk = 0u;
+                    if (on) {
+                        TX res[2];
+                        TX dummy[1];
+                        blend_level<TX, 3, 2, false>(f[i], lvl_x[g + i].scale, res, dummy);
+                        pk = pack_h2(to_f<TX>(res[0]), to_f<TX>(res[1]));
+                    }
+                    stage[lane * kStageRow + g + i] = pk;
+                }
+            }
+        }
+        stage_sync();
+
+        // ---- ambient net: [enc_x | enc_a] 96 -> 64 -> 64 -> 2, tanh (bias = W0[:, 32:] enc_a)
+        Acc a0, a1;
+        acc_bias(a0, bias_amb, h);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            f16x8 b0, b1;
+            stage_frags(stage, s, j, h, b0, b1);
+            hstep(a0, wl, KS_A0 + s, lane_off8, b0, b1);
+        }
+        acc_relu(a0);
+        acc_zero(a1);
+        hlayer_from_acc(a1, a0, wl, KS_A1, lane_off8);
+        acc_relu(a1);
+        float amb[2];
+        {
+            float part[2][2];
+            valu_out<2>(a1, lds + HOFF_A2, h, part);
+            amb[0] = tanhf(h ? part[1][0] : part[0][0]);
+            amb[1] = tanhf(h ? part[1][1] : part[0][1]);
+        }
+        if (p.ambient && live) {
+            p.ambient[2 * (size_t)sample] = amb[0];
+            p.ambient[2 * (size_t)sample + 1] = amb[1];
+        }
+
+        // ---- ambient grid: enc_w = encoder_ambient(ambient, bound=1) -> staging words 16..31 (no accumulator is live)
+        {
+            float in[2] = {(amb[0] + 1.0f) / 2.0f, (amb[1] + 1.0f) / 2.0f};
+            const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
+            LevelFetch<TW, 2, 2> f[kAmbGroup];
+#pragma unroll 1
+            for (int g = 0; g < 16; g += kAmbGroup) {
+                if (on) {
+#pragma unroll
+                    for (int i = 0; i < kAmbGroup; i++) {
+                        const LevelLds lv = lvl_w[g + i];
+                        issue_level<TW, 2, 2>(static_cast<const TW *>(p.gw.table) + (size_t)lv.offset * 2, in, lv.scale,
+                                              lv.resolution, lv.rows, p.gw.gridtype, false, 0, f[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kAmbGroup; i++) {
+                    uint32_t pk = 0u;
+                    if (on) {
+                        TW res[2];
+                        TW dummy[1];
+                        blend_level<TW, 2, 2, false>(f[i], lvl_w[g + i].scale, res, dummy);
+                        pk = pack_h2(to_f<TW>(res[0]), to_f<TW>(res[1]));
+                    }
+                    stage[lane * kStageRow + 16 + g + i] = pk;
+                }
+            }
+        }
+        stage_sync();
+
+        // ---- sigma net: [enc_x | enc_w | eye] 65 -> 64 -> 64 -> 1 + 64 (bias = W0[:, 64] eye); k-steps 0,1 read enc_x
+        // and 2,3 read enc_w from the staging row
+        acc_bias(a0, bias_sig, h);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            f16x8 b0, b1;
+            stage_frags(stage, s, j, h, b0, b1);
+            hstep(a0, wl, KS_S0 + s, lane_off8, b0, b1);
+        }
+        acc_relu(a0);
+        acc_zero(a1);
+        hlayer_from_acc(a1, a0, wl, KS_S1, lane_off8);
+        acc_relu(a1);
+        float sigma;
+        {
+            float part[2][1];
+            valu_out<1>(a1, lds + HOFF_S2R, h, part);
+            sigma = expf(h ? part[1][0] : part[0][0]);  // trunc_exp forward (activation.py:9-11)
+        }
+        acc_zero(a0);
+        hlayer_from_acc(a0, a1, wl, KS_S2, lane_off8);  // geo_feat (no activation)
+
+        // ---- color net: [SH(d) | geo_feat | ind_code] 84 -> 64 -> 3, sigmoid
+        stage_sync();
+        {
+            float sh[16];
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            if (live) {
+                dx = p.dirs[3 * (size_t)sample]; dy = p.dirs[3 * (size_t)sample + 1]; dz = p.dirs[3 * (size_t)sample + 2];
+            }
+            sh_basis<4>(dx, dy, dz, sh);
+#pragma unroll
+            for (int s = 0; s < 8; s++) stage[lane * kStageRow + s] = pack_h2(sh[2 * s], sh[2 * s + 1]);
+        }
+        stage_sync();
+        acc_bias(a1, bias_col, h);
+        {
+            f16x8 b0, b1;
+            stage_frags(stage, 0, j, h, b0, b1);
+            hstep(a1, wl, KS_C0, lane_off8, b0, b1);
+        }
+        hlayer_from_acc(a1, a0, wl, KS_C0 + 1, lane_off8);
+        acc_relu(a1);
+        {
+            float part[2][3];
+            valu_out<3>(a1, lds + HOFF_C1, h, part);
+            if (live) {
+                p.sigmas[sample] = sigma;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float x = h ? part[1][c] : part[0][c];
+                    p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-x));
+                }
+            }
+        }
+        stage_sync();  // the next tile's gathers overwrite the staging rows
+    }
+}
+
+void launch_fused_h16(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t blocks, hipStream_t s) {
+    const dim3 g(blocks), b(kFusedThreads);
+    if (gx_dtype == RN_F32 && gw_dtype == RN_F32) hipLaunchKernelGGL((k_nerf_fused_h16<float, float>), g, b, 0, s, p);
+    else if (gx_dtype == RN_F16 && gw_dtype == RN_F16) hipLaunchKernelGGL((k_nerf_fused_h16<__half, __half>), g, b, 0, s, p);
+    else if (gx_dtype == RN_F32) hipLaunchKernelGGL((k_nerf_fused_h16<float, __half>), g, b, 0, s, p);
+    else hipLaunchKernelGGL((k_nerf_fused_h16<__half, float>), g, b, 0, s, p);
+}
+
+void launch_pack_nerf_h16(const RawW &w, float *packed, hipStream_t s) {
+    const int n = kHSteps * kHStep + (kHPacked - kHMfmaFloats);
+    hipLaunchKernelGGL(k_pack_nerf_h16, dim3(div_up(n, 256)), dim3(256), 0, s, w, packed);
+}
+
+size_t packed_floats_h16() { return (size_t)kHPacked; }
+
+}  // namespace rn

@@ -54,11 +54,12 @@ ST_ACTIVE, ST_ITERS, ST_LIVE, ST_SLOTS = 4, 16, 17, 18
 
 _SIGS = {
     "rn_nerf_pack_weights": [C.POINTER(NerfWeightsT), _ptr, _ptr],
+    "rn_nerf_pack_weights_h16": [C.POINTER(NerfWeightsT), _ptr, _ptr],
     "rn_nerf_frame_bias": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_nerf_fused_forward": [_ptr, _ptr, _ptr, _u32, _ptr, C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _f32, _ptr,
-                              _ptr, _ptr, _ptr],
+                              _ptr, _ptr, C.c_int, _ptr],
     "rn_head_begin": [C.POINTER(HeadT), _ptr],
-    "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, _ptr],
+    "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, C.c_int, _ptr],
     "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
     "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
     "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
@@ -70,12 +71,14 @@ for _n, _a in _SIGS.items():
     _f.argtypes = _a
     _f.restype = C.c_int
 _lib.rn_nerf_packed_floats.restype = C.c_size_t
+_lib.rn_nerf_packed_floats_h16.restype = C.c_size_t
 _lib.rn_nerf_bias_floats.restype = C.c_size_t
 _lib.rn_torso_packed_floats.restype = C.c_size_t
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["rn_nerf_packed_floats", "rn_nerf_bias_floats", "rn_torso_packed_floats"])
+    return sorted(list(_SIGS) + ["rn_nerf_packed_floats", "rn_nerf_packed_floats_h16", "rn_nerf_bias_floats",
+                                 "rn_torso_packed_floats"])
 
 
 def _grid_desc(enc, table):
@@ -115,7 +118,9 @@ class FusedState:
             raise RuntimeError("fused engine: unsupported network shape; use engine='ops'")
         self.model = model
         self.dev = model.density_bitfield.device
-        self.packed = torch.empty(int(_lib.rn_nerf_packed_floats()), dtype=torch.float32, device=self.dev)
+        n_packed = max(int(_lib.rn_nerf_packed_floats()), int(_lib.rn_nerf_packed_floats_h16()))
+        self.packed = torch.empty(n_packed, dtype=torch.float32, device=self.dev)
+        self.mlp_dtype = hip.RN_F32
         self.bias = torch.empty(int(_lib.rn_nerf_bias_floats()), dtype=torch.float32, device=self.dev)
         self.tpacked = (torch.empty(int(_lib.rn_torso_packed_floats()), dtype=torch.float32, device=self.dev)
                         if model.torso else None)
@@ -136,7 +141,9 @@ class FusedState:
         tables = [self.model.encoder.embeddings, self.model.encoder_ambient.embeddings]
         if self.model.torso:
             tables.append(self.model.torso_encoder.embeddings)
-        versions = tuple((w._version, w.data_ptr()) for w in ws + tables)
+        # opt.mlp_dtype = "f16": contractions on the 16-bit matrix cores (fp32 accumulate), the reference's -O arithmetic
+        mlp = {"f32": hip.RN_F32, "f16": hip.RN_F16}[getattr(getattr(self.model, "opt", None), "mlp_dtype", "f32")]
+        versions = tuple((w._version, w.data_ptr()) for w in ws + tables) + (mlp,)
         if versions == self._versions:
             return
         m = self.model
@@ -149,7 +156,9 @@ class FusedState:
         self.nw.audio_dim, self.nw.has_eye, self.nw.ind_dim = m.audio_dim, int(m.exp_eye), m.individual_dim
         assert tuple(ws[0].shape) == (64, 32 + m.audio_dim) and tuple(ws[3].shape) == (64, 64 + int(m.exp_eye))
         assert tuple(ws[5].shape) == (65, 64) and tuple(ws[6].shape) == (64, 80 + m.individual_dim)
-        hip.call("rn_nerf_pack_weights", C.byref(self.nw), hip.ptr(self.packed), hip.stream())
+        self.mlp_dtype = mlp
+        hip.call("rn_nerf_pack_weights_h16" if mlp == hip.RN_F16 else "rn_nerf_pack_weights", C.byref(self.nw),
+                 hip.ptr(self.packed), hip.stream())
         if m.torso:
             self.tw = TorsoWeightsT()
             (self.tw.def_w0, self.tw.def_w1, self.tw.def_w2, self.tw.tor_w0, self.tw.tor_w1,
@@ -246,7 +255,7 @@ def network_forward(model, xyzs, dirs, enc_a, ind_code, eye, deltas=None, want_a
         deltas = deltas.contiguous()
     hip.call("rn_nerf_fused_forward", hip.ptr(xyzs), hip.ptr(dirs), hip.ptr(deltas), M, None, C.byref(st.gx), C.byref(st.gw),
              hip.ptr(st.packed), hip.ptr(st.bias), float(model.bound), hip.ptr(sigmas), hip.ptr(rgbs), hip.ptr(ambient),
-             hip.stream())
+             st.mlp_dtype, hip.stream())
     return sigmas, rgbs, ambient
 
 
@@ -290,7 +299,7 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     shard = getattr(model, "shard_schedule", None)
     if shard is None:
         hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0,
-                 int(max_steps), s)
+                 int(max_steps), st.mlp_dtype, s)
     else:
         # This call renders a shard of a frame (tile-parallel): the step schedule must be the whole frame's, so the
         # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.
@@ -298,7 +307,7 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
         total = torch.empty(1, dtype=torch.int32, device=dev)
         for it in range(int(max_steps)):
             hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias),
-                     it, 1, s)
+                     it, 1, st.mlp_dtype, s)
             bank = ((it + 1) & 1) * 8
             total.copy_(st.state[bank:bank + 1])
             group.all_reduce(total)

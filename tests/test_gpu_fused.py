@@ -104,6 +104,79 @@ def test_fused_frame_matches_oracle(po, hiplib, size):
 HASH19 = dict(xyz_grid="hashgrid", xyz_log2_hashmap_size=19)   # BASELINE config[1]
 
 
+# ---- opt-in 16-bit matrix-core variant (opt.mlp_dtype = "f16", include/radnerf_fused.h) ---------------------------
+# Checker: the oracle run under the same arithmetic (orc_nerf_forward_mp16: fp16 operands into the contractions, fp32
+# accumulation).  Two independent implementations of that arithmetic differ only by fp32 summation order and by the
+# rare fp16 rounding flip it causes (an activation that sits on a rounding boundary moves by one fp16 ulp, up to 2^-7
+# for hidden values in [8, 16)): 99.9 % of the outputs agree to 1e-4 (sigma: rel 1e-3), every output to 1e-2 (sigma: rel 3e-2).
+# Against the fp32 oracle the mode itself costs at most ~1e-2 per sample and <= 4e-3 (one 8-bit step) per rendered
+# pixel -- stated here, measured ~1e-3.
+def _close_up_to_rounding_flips(got, want, bulk_atol, rel=False):
+    err = np.abs(got - want) / (np.abs(want) if rel else 1.0)
+    assert float((err <= bulk_atol).mean()) >= 0.999, float((err <= bulk_atol).mean())
+    assert float(err.max()) <= (3e-2 if rel else 1e-2), float(err.max())     # sigma = exp(raw) turns abs into rel
+
+
+@pytest.mark.parametrize("M", [1, 64, 65, 5000, 100003])
+@pytest.mark.parametrize("grid", ["tiled16", "hash19"])
+def test_fused_f16_network_matches_mp16_oracle(po, hiplib, M, grid):
+    from radnerf import fused
+    kw = HASH19 if grid == "hash19" else {}
+    scene = _scene(16, "fused", mlp_dtype="f16", **kw)
+    m = scene.model
+    rng = np.random.default_rng(M + 7)
+    x = rng.uniform(-0.7, 0.7, (M, 3)).astype(np.float32)
+    if M > 10:
+        x[3] = (1.5, 0.0, 0.0)   # outside [-bound, bound] -> enc_x = 0
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    enc_a = rng.standard_normal((1, 64)).astype(np.float32)
+    eye = np.array([[0.25]], np.float32)
+    c = m.individual_codes[0].detach()
+    with torch.no_grad():
+        sigma, color, amb = fused.network_forward(m, torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(),
+                                                  torch.from_numpy(enc_a).cuda(), c, torch.from_numpy(eye).cuda())
+    om = po.model_from_module(m)
+    es, ec, ea = po.nerf_forward(om, x, d, enc_a, c.cpu().numpy(), eye, mlp_dtype="f16")
+    _close_up_to_rounding_flips(amb.cpu().numpy(), ea, 1e-4)
+    _close_up_to_rounding_flips(sigma.cpu().numpy(), es, 1e-3, rel=True)
+    _close_up_to_rounding_flips(color.cpu().numpy(), ec, 1e-4)
+    fs, fc, fa = po.nerf_forward(om, x, d, enc_a, c.cpu().numpy(), eye)            # the fp32 truth
+    assert np.abs(color.cpu().numpy() - fc).max() < 1e-2 and np.abs(amb.cpu().numpy() - fa).max() < 1e-2
+    assert np.abs(sigma.cpu().numpy() / fs - 1).max() < 3e-2
+
+
+@pytest.mark.parametrize("size", [64, 160])
+def test_fused_f16_frame_within_one_8bit_step_of_fp32_oracle(po, hiplib, size):
+    scene = _scene(size, "fused", mlp_dtype="f16")
+    worst = 0.0
+    for i in range(2):
+        f = scene.frame(i)
+        with torch.no_grad():
+            out = scene.render(i)
+        img, dep, stats = _oracle_frame(po, scene, f, scene.model.enc_a)
+        got = out["image"].reshape(-1, 3).cpu().numpy()
+        worst = max(worst, float(np.abs(got - img).max()))
+        assert scene.model.last_stats["iterations"] == stats["iterations"]
+    assert worst <= 4e-3, worst
+
+
+def test_fused_f16_and_f32_share_one_model(hiplib):
+    """Switching opt.mlp_dtype re-packs the weight image (FusedState.refresh keys on it)."""
+    a = _scene(48, "fused")
+    with torch.no_grad():
+        i32 = a.render(0)["image"].clone()
+        a.model.opt.mlp_dtype = "f16"
+        a.model.enc_a = None
+        i16 = a.render(0)["image"].clone()
+        a.model.opt.mlp_dtype = "f32"
+        a.model.enc_a = None
+        back = a.render(0)["image"].clone()
+    assert torch.equal(i32, back)
+    d = (i32 - i16).abs().max().item()
+    assert 0 < d <= 4e-3, d
+
+
 @pytest.mark.parametrize("engine", ["fused", "ops"])
 def test_hash_grid_frame_matches_oracle(po, hiplib, engine):
     """BASELINE config[1] names an instant-ngp hash grid with T=2^19 for xyz: levels 5..15 go through fast_hash
