@@ -26,6 +26,11 @@
 
 namespace rn {
 
+#ifndef RN_FUSED_PAIR_HASHED
+#define RN_FUSED_PAIR_HASHED 1
+#endif
+constexpr bool kPairHashed = RN_FUSED_PAIR_HASHED;  // aligned x-pair loads on hashed levels inside the fused kernels
+
 // ---- packed weight image (floats) --------------------------------------------------------------------
 // MFMA layers: [step][h][col j][row tile] -> lane (j, h) reads one float2 per step.
 constexpr int kStep = 128;                           // floats per MFMA step (2 halves x 32 lanes x 2 row tiles)
@@ -127,7 +132,7 @@ __device__ __forceinline__ void level_features(const void *table, const LevelLds
     if (on) {
         TT res[2];
         TT dummy[1];
-        encode_level<TT, D, 2, false>(static_cast<const TT *>(table) + (size_t)lv.offset * 2, in, lv.scale, lv.resolution,
+        encode_level<TT, D, 2, false>(static_cast<const TT *>(table), lv.offset, in, lv.scale, lv.resolution,
                                       lv.rows, gridtype, false, 0, res, dummy);
         f0 = to_f<TT>(res[0]);
         f1 = to_f<TT>(res[1]);
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
             auto issue = [&](int l, LevelFetch<TX, 3, 2> &f) {
                 if (on) {
                     const LevelLds lv = lvl_x[l];
-                    issue_level<TX, 3, 2>(static_cast<const TX *>(p.gx.table) + (size_t)lv.offset * 2, in, lv.scale,
+                    issue_level<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), lv.offset, in, lv.scale,
                                           lv.resolution, lv.rows, p.gx.gridtype, false, 0, f);
                 }
             };
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
             auto issue = [&](int l, LevelFetch<TW, 2, 2> &f) {
                 if (on) {
                     const LevelLds lv = lvl_w[l];
-                    issue_level<TW, 2, 2>(static_cast<const TW *>(p.gw.table) + (size_t)lv.offset * 2, in, lv.scale,
+                    issue_level<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), lv.offset, in, lv.scale,
                                           lv.resolution, lv.rows, p.gw.gridtype, false, 0, f);
                 }
             };

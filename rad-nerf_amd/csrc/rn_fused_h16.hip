@@ -17,6 +17,11 @@
 
 namespace rn {
 
+#ifndef RN_FUSED_PAIR_HASHED
+#define RN_FUSED_PAIR_HASHED 1
+#endif
+constexpr bool kPairHashed = RN_FUSED_PAIR_HASHED;  // aligned x-pair loads on hashed levels inside the fused kernels
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
 #pragma unroll
                     for (int i = 0; i < kXyzGroup; i++) {
                         const LevelLds lv = lvl_x[g + i];
-                        issue_level<TX, 3, 2>(static_cast<const TX *>(p.gx.table) + (size_t)lv.offset * 2, in, lv.scale,
+                        issue_level<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), lv.offset, in, lv.scale,
                                               lv.resolution, lv.rows, p.gx.gridtype, false, 0, f[i]);
                     }
                 }
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
 #pragma unroll
                     for (int i = 0; i < kAmbGroup; i++) {
                         const LevelLds lv = lvl_w[g + i];
-                        issue_level<TW, 2, 2>(static_cast<const TW *>(p.gw.table) + (size_t)lv.offset * 2, in, lv.scale,
+                        issue_level<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), lv.offset, in, lv.scale,
                                               lv.resolution, lv.rows, p.gw.gridtype, false, 0, f[i]);
                     }
                 }

@@ -54,7 +54,7 @@ k_grid_fwd_level(const float *__restrict__ inputs, const T *__restrict__ table, 
     } else {
         const uint32_t off = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-        encode_level<T, D, C, DYDX>(table + (size_t)off * C, in, lc.scale[level], lc.resolution[level], hashmap_size,
+        encode_level<T, D, C, DYDX>(table, off, in, lc.scale[level], lc.resolution[level], hashmap_size,
                                     gridtype, align_corners, interp, results, grads);
     }
     T *o = (LAYOUT == RN_LAYOUT_LBC) ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;
@@ -89,7 +89,7 @@ k_grid_fwd_sample(const float *__restrict__ inputs, const T *__restrict__ table,
                 for (uint32_t i = 0; i < D * C; i++) grads[i] = from_f<T>(0.0f);
             }
         } else {
-            encode_level<T, D, C, DYDX>(table + (size_t)off * C, in, lc.scale[level], lc.resolution[level], next - off,
+            encode_level<T, D, C, DYDX>(table, off, in, lc.scale[level], lc.resolution[level], next - off,
                                         gridtype, align_corners, interp, results, grads);
         }
         T *o = (LAYOUT == RN_LAYOUT_LBC) ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;

@@ -70,8 +70,11 @@ struct RowWords {
     static_assert(bytes == 2 || bytes == 4 || bytes == 8 || bytes == 16 || bytes == 32, "unsupported row width");
 };
 
+// The loaders address `table` (a wave-uniform pointer: kernel argument) + a 32-bit byte offset, which the compiler
+// turns into the scalar-base form of global_load (one offset VGPR per load instead of a 64-bit address pair).
 template <typename T, uint32_t C>
-__device__ __forceinline__ void load_row_words(const T *p, uint32_t (&w)[RowWords<T, C>::W]) {
+__device__ __forceinline__ void load_row_words(const T *table, uint32_t byte_off, uint32_t (&w)[RowWords<T, C>::W]) {
+    const char *p = reinterpret_cast<const char *>(table) + byte_off;
     constexpr uint32_t bytes = RowWords<T, C>::bytes;
     if constexpr (bytes == 2) {
         w[0] = *reinterpret_cast<const uint16_t *>(p);
@@ -92,7 +95,9 @@ __device__ __forceinline__ void load_row_words(const T *p, uint32_t (&w)[RowWord
 // Two adjacent rows with one load of 2*C scalars; the address is only guaranteed to be row-aligned
 // (C * sizeof(T)), which global loads on gfx950 accept (dword alignment is all the hardware needs).
 template <typename T, uint32_t C>
-__device__ __forceinline__ void load_pair_words(const T *p, uint32_t (&a)[RowWords<T, C>::W], uint32_t (&b)[RowWords<T, C>::W]) {
+__device__ __forceinline__ void load_pair_words(const T *table, uint32_t byte_off, uint32_t (&a)[RowWords<T, C>::W],
+                                                uint32_t (&b)[RowWords<T, C>::W]) {
+    const char *p = reinterpret_cast<const char *>(table) + byte_off;
     constexpr uint32_t bytes = RowWords<T, C>::bytes * 2;
     constexpr uint32_t words = bytes / 4;
     if constexpr (bytes == 4) {  // two fp16 scalars
@@ -193,11 +198,13 @@ struct LevelFetch {
 // in x sit in adjacent rows (unless the modulo wraps): one load of 2*C scalars fetches both.  On hashed levels the x
 // prime is 1 (gridencoder.cu:52), so for an even lattice x the two x-neighbours hash to rows r and r ^ 1 -- the two
 // halves of one aligned 2-row block (every level size is a multiple of 8, so the modulo keeps them together): one
-// aligned load fetches both, in table order; `swapped` tells blend_level which half is which.  Odd x: two loads.
-template <typename T, uint32_t D, uint32_t C>
-__device__ __forceinline__ void issue_level(const T *__restrict__ grid, const float (&in)[D], float scale,
-                                            uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
+// aligned load fetches both, in table order; `swapped` tells blend_level which half is which.  Odd x: two loads
+// (PAIR_HASHED = false keeps hashed levels to plain row loads: no divergent branch, for callers that are not load-bound).
+template <typename T, uint32_t D, uint32_t C, bool PAIR_HASHED = true>
+__device__ __forceinline__ void issue_level(const T *__restrict__ table, uint32_t level_row, const float (&in)[D],
+                                            float scale, uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
                                             bool align_corners, uint32_t interp, LevelFetch<T, D, C> &f) {
+    constexpr uint32_t kRowBytes = sizeof(T) * C;   // tables stay far below 4 GB: byte offsets fit 32 bits
     constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
     uint32_t pos_grid[D];
     lattice_pos<D>(in, scale, align_corners, interp, f.pos, f.pos_deriv, pos_grid);
@@ -224,20 +231,31 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ grid, const fl
     }
 
     constexpr bool kCanPair = sizeof(T) * C * 2 <= 32;
+    constexpr uint32_t P = 1u << (D - 1);  // x-pairs of corners
     f.swapped = 0;
     if (!hashed) {
+        uint32_t r0[P], r1[P];
+        bool adjacent = kCanPair;
 #pragma unroll
-        for (uint32_t idx = 0; idx < (1u << D); idx += 2) {
+        for (uint32_t q = 0; q < P; q++) {
             uint32_t base = 0;
 #pragma unroll
-            for (uint32_t d = 1; d < D; d++) base += ((idx >> d) & 1u) ? t1[d] : t0[d];
-            const uint32_t row0 = fast_mod(base + t0[0], hashmap_size);
-            const uint32_t row1 = fast_mod(base + t1[0], hashmap_size);
-            if (kCanPair && row1 == row0 + 1) {
-                load_pair_words<T, C>(grid + (size_t)row0 * C, f.rows[idx], f.rows[idx + 1]);
-            } else {
-                load_row_words<T, C>(grid + (size_t)row0 * C, f.rows[idx]);
-                load_row_words<T, C>(grid + (size_t)row1 * C, f.rows[idx + 1]);
+            for (uint32_t d = 1; d < D; d++) base += ((q >> (d - 1)) & 1u) ? t1[d] : t0[d];
+            r0[q] = fast_mod(base + t0[0], hashmap_size);
+            r1[q] = fast_mod(base + t1[0], hashmap_size);
+            adjacent = adjacent && r1[q] == r0[q] + 1;
+        }
+        // one wave-uniform decision for the level (the modulo wraps on a handful of samples only), so the loads of a
+        // level sit in one basic block and the scheduler can batch them
+        if (kCanPair && __builtin_amdgcn_ballot_w64(!adjacent) == 0ull) {
+#pragma unroll
+            for (uint32_t q = 0; q < P; q++)
+                load_pair_words<T, C>(table, (level_row + r0[q]) * kRowBytes, f.rows[2 * q], f.rows[2 * q + 1]);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < P; q++) {
+                load_row_words<T, C>(table, (level_row + r0[q]) * kRowBytes, f.rows[2 * q]);
+                load_row_words<T, C>(table, (level_row + r1[q]) * kRowBytes, f.rows[2 * q + 1]);
             }
         }
     } else {
@@ -248,12 +266,12 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ grid, const fl
             for (uint32_t d = 1; d < D; d++) base ^= ((idx >> d) & 1u) ? t1[d] : t0[d];
             const uint32_t row0 = fast_mod(base ^ t0[0], hashmap_size);
             const uint32_t row1 = fast_mod(base ^ t1[0], hashmap_size);
-            if (kCanPair && (row0 ^ row1) == 1u) {
-                load_pair_words<T, C>(grid + (size_t)(row0 & ~1u) * C, f.rows[idx], f.rows[idx + 1]);
+            if (PAIR_HASHED && kCanPair && (row0 ^ row1) == 1u) {
+                load_pair_words<T, C>(table, (level_row + (row0 & ~1u)) * kRowBytes, f.rows[idx], f.rows[idx + 1]);
                 f.swapped |= (row0 & 1u) << (idx >> 1);
             } else {
-                load_row_words<T, C>(grid + (size_t)row0 * C, f.rows[idx]);
-                load_row_words<T, C>(grid + (size_t)row1 * C, f.rows[idx + 1]);
+                load_row_words<T, C>(table, (level_row + row0) * kRowBytes, f.rows[idx]);
+                load_row_words<T, C>(table, (level_row + row1) * kRowBytes, f.rows[idx + 1]);
             }
         }
     }
@@ -334,12 +352,12 @@ __device__ __forceinline__ void blend_level(const LevelFetch<T, D, C> &f, float 
 
 // issue + blend back to back (callers that do not pipeline)
 template <typename T, uint32_t D, uint32_t C, bool DYDX>
-__device__ __forceinline__ void encode_level(const T *__restrict__ grid, const float (&in)[D], float scale,
+__device__ __forceinline__ void encode_level(const T *__restrict__ table, uint32_t level_row, const float (&in)[D], float scale,
                                              uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype,
                                              bool align_corners, uint32_t interp, T (&results)[C],
                                              T (&grads)[DYDX ? D * C : 1]) {
     LevelFetch<T, D, C> f;
-    issue_level<T, D, C>(grid, in, scale, resolution, hashmap_size, gridtype, align_corners, interp, f);
+    issue_level<T, D, C>(table, level_row, in, scale, resolution, hashmap_size, gridtype, align_corners, interp, f);
     blend_level<T, D, C, DYDX>(f, scale, results, grads);
 }
 
