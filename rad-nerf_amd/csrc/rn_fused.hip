@@ -187,9 +187,9 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                     on = on && !(in[d] < 0 || in[d] > 1);
                 }
             }
-            // software pipeline: the row loads of level l+1 are in flight while level l is blended and fed to
-            // the matrix cores (two static fetch buffers, loop unrolled by two)
-            LevelFetch<TX, 3, 2> fa, fb;
+            // One level at a time: the partner wave on the SIMD covers the load latency (a two-deep software pipeline
+            // was measured equal within noise and cost 19 spilled VGPRs = 4 MB of scratch writes per launch).
+            LevelFetch<TX, 3, 2> fa;
             auto issue = [&](int l, LevelFetch<TX, 3, 2> &f) {
                 if (on) {
                     const LevelLds lv = lvl_x[l];
@@ -210,13 +210,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                 step64(a0, lds + OFF_A0, l, lane_off, b0, b1);
                 step64(a2, lds + OFF_S0, l, lane_off, b0, b1);
             };
-            issue(0, fa);
 #pragma unroll 1
-            for (int l = 0; l < 16; l += 2) {
-                issue(l + 1, fb);
+            for (int l = 0; l < 16; l++) {
+                issue(l, fa);
                 consume(l, fa);
-                if (l + 2 < 16) issue(l + 2, fa);
-                consume(l + 1, fb);
             }
         }
 
@@ -241,7 +238,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
         {
             float in[2] = {(amb[0] + 1.0f) / 2.0f, (amb[1] + 1.0f) / 2.0f};
             const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
-            LevelFetch<TW, 2, 2> fa, fb;
+            LevelFetch<TW, 2, 2> fa;
             auto issue = [&](int l, LevelFetch<TW, 2, 2> &f) {
                 if (on) {
                     const LevelLds lv = lvl_w[l];
@@ -261,13 +258,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                 to_b_operands(f0, f1, b0, b1);
                 step64(a2, lds + OFF_S0, 16 + l, lane_off, b0, b1);
             };
-            issue(0, fa);
 #pragma unroll 1
-            for (int l = 0; l < 16; l += 2) {
-                issue(l + 1, fb);
+            for (int l = 0; l < 16; l++) {
+                issue(l, fa);
                 consume(l, fa);
-                if (l + 2 < 16) issue(l + 2, fa);
-                consume(l + 1, fb);
             }
         }
 

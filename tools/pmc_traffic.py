@@ -5,7 +5,8 @@ Units / corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB;
 the bytes of a wide coalesced streaming read, so it is doubled (an upper bound for this kernel's mix of scalar
 coalesced reads and L2-resident gathers -- uncalibrated for that pattern); WRITE_SIZE is exact.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/traffic.json
+    python tools/pmc_traffic.py profiles/traffic.json FETCH_DIR WRITE_DIR [FETCH_DIR2 WRITE_DIR2 ...]
+(one FETCH/WRITE pair per profiled bench configuration; kernels found in a later pair do not overwrite earlier ones)
 """
 import collections
 import csv
@@ -13,7 +14,7 @@ import glob
 import json
 import sys
 
-KEYS = {"nerf_fused": "k_nerf_fused", "grid_encode_xyz": "k_grid_fwd_sample<float, 3u", "torso_fused": "k_torso_fused",
+KEYS = {"nerf_fused": "k_nerf_fused<", "nerf_fused_h16": "k_nerf_fused_h16<", "grid_encode_xyz": "k_grid_fwd_sample<float, 3u", "torso_fused": "k_torso_fused",
         "head_march": "k_head_march", "head_composite": "k_head_composite"}
 
 
@@ -27,10 +28,19 @@ def collect(d, counter):
 
 
 def main():
-    fetch_dir, write_dir, dst = sys.argv[1:4]
-    fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    dst, dirs = sys.argv[1], sys.argv[2:]
     res = {}
+    for fetch_dir, write_dir in zip(dirs[0::2], dirs[1::2]):
+        fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+        pairs(res, fetch, write)
+    json.dump(res, open(dst, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+def pairs(res, fetch, write):
     for key, pat in KEYS.items():
+        if key in res:
+            continue
         fv = [v for k, vs in fetch.items() if pat in k for v in vs]
         wv = [v for k, vs in write.items() if pat in k for v in vs]
         if not fv or not wv:
@@ -40,8 +50,6 @@ def main():
                         hbm_bytes_per_launch=(2.0 * f_kib + w_kib) * 1024.0,
                         hbm_bytes_per_launch_uncorrected=(f_kib + w_kib) * 1024.0,
                         note="mean over every launch of the kernel in the profiled bench run (incl. zero-sample launches)")
-    json.dump(res, open(dst, "w"), indent=1)
-    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
