@@ -145,6 +145,34 @@ int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid
 int rn_blend_frame(float *image, const float *weights_sum, const float *bg, float *depth, const float *nears,
                    const float *fars, uint32_t N, uint8_t *image_u8, rn_stream_t stream);
 
+/* ---- audio code ------------------------------------------------------------------------------
+ * NeRFNetwork.encode_audio (nerf/network.py:170-185) = AudioNet (nerf/network.py:41-67: 4 x Conv1d(k3, s2, p1) +
+ * LeakyReLU(0.02) over the 16-sample window, Linear-LeakyReLU-Linear) on each of the 8 frames of the attention window,
+ * then AudioAttNet (nerf/network.py:10-37: 5 x Conv1d(k3, s1, p1) + LeakyReLU(0.02) over the 8 codes, Linear(8,8),
+ * softmax, weighted sum) -- ~45 tiny PyTorch launches per frame in the reference, ONE workgroup per window here.
+ * All weights are the modules' own tensors (Conv1d [cout, cin, 3] + bias, Linear [out, in] + bias), fp32. */
+typedef struct {
+    const float *conv_w[4], *conv_b[4];         /* audio_net.encoder_conv.{0,2,4,6}: dim_in->32->32->64->64 */
+    const float *fc_w[2], *fc_b[2];             /* audio_net.encoder_fc1.{0,2}: 64->64->dim_aud */
+    const float *att_conv_w[5], *att_conv_b[5]; /* audio_att_net.attentionConvNet.{0,2,4,6,8}: dim_aud->16->8->4->2->1 */
+    const float *att_fc_w, *att_fc_b;           /* audio_att_net.attentionNet.0: [8,8], [8] */
+    uint32_t dim_in, dim_aud, has_att;          /* has_att = 0: one frame per window, no attention (opt.att == 0) */
+} rn_audio_weights_t;
+#define RN_AUDIO_SEQ 8   /* frames per attention window */
+#define RN_AUDIO_WIN 16  /* feature samples per frame */
+/* enc[i, :] = encode_audio(auds[i]) for n windows; auds: [n, (has_att ? 8 : 1), dim_in, 16] as NeRFRenderer.run_cuda
+ * receives them (nerf/renderer.py:186). */
+int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, rn_stream_t stream);
+/* The same for n consecutive frames (first + i) mod T of a feature stream feats [T, dim_in, 16]: the windows are cut on
+ * the device exactly as get_audio_features(att_mode=2) does (nerf/utils.py:56-72: frames index-4 .. index+3, zero rows
+ * outside the stream).  Needs T >= 8 and has_att. */
+int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint32_t T, uint32_t first, uint32_t n,
+                           float *enc, rn_stream_t stream);
+/* Lip smoothing (nerf/renderer.py:190-194) folded over n codes in order:
+ * state = state_valid ? lambda * state + (1 - lambda) * enc[i] : enc[i]; state [dim] is updated in place. */
+int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,
+                    rn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,219 @@
+// rn_audio.hip -- the per-frame audio code as one kernel (C ABI: include/radnerf_fused.h, "audio code").
+//
+// What is computed: NeRFNetwork.encode_audio (nerf/network.py:170-185) = AudioNet (:41-67) on the 8 frames of the
+// attention window + AudioAttNet (:10-37); then the lip-smoothing EMA of nerf/renderer.py:190-194 (rn_audio_smooth).
+// How: one 256-thread workgroup per window.  Activations live in LDS ([frame][channel][position]); each layer's
+// weights are staged into LDS with coalesced loads, then every thread produces outputs in a strided loop.  ~0.6 M MAC
+// per window: the point is latency (1 launch instead of ~45) -- which is also what lets a frame-parallel rank advance
+// the smoothing state through the frames other ranks render without paying 45 launches for each of them.
+#include "rn_common.h"
+
+#include "../../include/radnerf_fused.h"
+
+namespace rn {
+
+constexpr int kAudioThreads = 256;
+constexpr int kSeq = RN_AUDIO_SEQ, kWin = RN_AUDIO_WIN;
+constexpr int kMaxDimIn = 64;     // dim_in is 29 / 32 / 44 (nerf/network.py:112-117)
+constexpr int kMaxWeights = 64 * 64 * 3;  // largest layer: conv 64 -> 64, k = 3
+
+struct AudioW {
+    const float *conv_w[4], *conv_b[4], *fc_w[2], *fc_b[2], *att_conv_w[5], *att_conv_b[5], *att_fc_w, *att_fc_b;
+    uint32_t dim_in, dim_aud, has_att;
+};
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : 0.02f * v; }  // nn.LeakyReLU(0.02)
+
+__device__ __forceinline__ void stage(float *dst, const float *__restrict__ src, int n) {
+    __syncthreads();  // previous users of dst are done
+    for (int i = threadIdx.x; i < n; i += kAudioThreads) dst[i] = src[i];
+    __syncthreads();
+}
+
+// Conv1d(kernel 3, padding 1) + LeakyReLU over `frames` independent [cin, len_in] maps held in LDS.
+// in: [frames][cin][len_in], out: [frames][cout][len_out], len_out = (len_in - 1) / stride + 1; w: [cout][cin][3] in LDS.
+__device__ __forceinline__ void conv3(const float *in, float *out, const float *w, const float *__restrict__ bias, int frames,
+                                      int cin, int cout, int len_in, int stride) {
+    const int len_out = (len_in - 1) / stride + 1;
+    const int total = frames * cout * len_out;
+    for (int o = threadIdx.x; o < total; o += kAudioThreads) {
+        const int pos = o % len_out, co = (o / len_out) % cout, f = o / (len_out * cout);
+        const float *x = in + (size_t)f * cin * len_in;
+        const float *wr = w + (size_t)co * cin * 3;
+        const int c0 = pos * stride - 1;
+        float acc = bias[co];
+        for (int ci = 0; ci < cin; ci++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int p = c0 + k;
+                if (p >= 0 && p < len_in) acc += wr[ci * 3 + k] * x[ci * len_in + p];
+            }
+        }
+        out[o] = leaky(acc);
+    }
+}
+
+// rows: y[f][o] = act(b[o] + sum_k W[o][k] x[f][k]); w [dout][din] in LDS
+__device__ __forceinline__ void linear(const float *in, float *out, const float *w, const float *__restrict__ bias, int frames,
+                                       int din, int dout, bool act) {
+    for (int o = threadIdx.x; o < frames * dout; o += kAudioThreads) {
+        const int f = o / dout, r = o % dout;
+        float acc = bias[r];
+        for (int k = 0; k < din; k++) acc += w[r * din + k] * in[f * din + k];
+        out[o] = act ? leaky(acc) : acc;
+    }
+}
+
+// window source: explicit windows [n][frames][dim_in][16], or cut from a stream [T][dim_in][16] (nerf/utils.py:56-72)
+struct Source {
+    const float *base;
+    uint32_t T, first;
+    int from_stream;
+};
+
+__global__ void __launch_bounds__(kAudioThreads) k_audio_encode(AudioW w, Source src, float *__restrict__ enc) {
+    __shared__ float wts[kMaxWeights];
+    __shared__ float bufA[kSeq * kMaxDimIn * kWin];  // ping
+    __shared__ float bufB[kSeq * 32 * 8];             // pong (largest: conv1 output)
+    __shared__ float codes[kSeq * 64];
+    const int frames = w.has_att ? kSeq : 1;
+    const int cin0 = (int)w.dim_in, A = (int)w.dim_aud;
+    const uint32_t win = blockIdx.x;
+
+    // the window's input maps: x[:, :, 8 - 8 : 8 + 8] of nerf/network.py:62-63 is the whole 16-sample frame
+    for (int i = threadIdx.x; i < frames * cin0 * kWin; i += kAudioThreads) {
+        float v;
+        if (src.from_stream) {
+            const int f = i / (cin0 * kWin), rest = i % (cin0 * kWin);
+            const int centre = (int)((src.first + win) % src.T);
+            const int g = centre - 4 + f;  // frames index-4 .. index+3, zero outside the stream
+            v = (g >= 0 && g < (int)src.T) ? src.base[(size_t)g * cin0 * kWin + rest] : 0.0f;
+        } else {
+            v = src.base[(size_t)win * frames * cin0 * kWin + i];
+        }
+        bufA[i] = v;
+    }
+    // AudioNet.encoder_conv: dim_in -> 32 -> 32 -> 64 -> 64, lengths 16 -> 8 -> 4 -> 2 -> 1
+    stage(wts, w.conv_w[0], 32 * cin0 * 3);
+    conv3(bufA, bufB, wts, w.conv_b[0], frames, cin0, 32, 16, 2);
+    stage(wts, w.conv_w[1], 32 * 32 * 3);
+    conv3(bufB, bufA, wts, w.conv_b[1], frames, 32, 32, 8, 2);
+    stage(wts, w.conv_w[2], 64 * 32 * 3);
+    conv3(bufA, bufB, wts, w.conv_b[2], frames, 32, 64, 4, 2);
+    stage(wts, w.conv_w[3], 64 * 64 * 3);
+    conv3(bufB, bufA, wts, w.conv_b[3], frames, 64, 64, 2, 2);  // -> [frames][64][1]
+    // encoder_fc1: Linear(64, 64) + LeakyReLU, Linear(64, dim_aud)
+    stage(wts, w.fc_w[0], 64 * 64);
+    linear(bufA, bufB, wts, w.fc_b[0], frames, 64, 64, true);
+    stage(wts, w.fc_w[1], A * 64);
+    linear(bufB, codes, wts, w.fc_b[1], frames, 64, A, false);
+    __syncthreads();
+    if (!w.has_att) {
+        for (int i = threadIdx.x; i < A; i += kAudioThreads) enc[(size_t)win * A + i] = codes[i];
+        return;
+    }
+    // AudioAttNet: x [8, A] -> permute -> [A channels][8 positions]
+    for (int i = threadIdx.x; i < A * kSeq; i += kAudioThreads) bufA[i] = codes[(i % kSeq) * A + i / kSeq];
+    const int chans[6] = {A, 16, 8, 4, 2, 1};
+    float *a = bufA, *b = bufB;
+    for (int l = 0; l < 5; l++) {
+        stage(wts, w.att_conv_w[l], chans[l + 1] * chans[l] * 3);
+        conv3(a, b, wts, w.att_conv_b[l], 1, chans[l], chans[l + 1], kSeq, 1);
+        float *t = a; a = b; b = t;
+    }
+    __syncthreads();  // a: [1][8] scores
+    // attentionNet: Linear(8, 8) + Softmax(dim=1), then sum_t y[t] * x[t, :]
+    __shared__ float att[kSeq];
+    if (threadIdx.x < kSeq) {
+        float acc = w.att_fc_b[threadIdx.x];
+        for (int k = 0; k < kSeq; k++) acc += w.att_fc_w[threadIdx.x * kSeq + k] * a[k];
+        att[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = att[0];
+        for (int t = 1; t < kSeq; t++) m = fmaxf(m, att[t]);
+        float e[kSeq], s = 0.0f;
+        for (int t = 0; t < kSeq; t++) { e[t] = expf(att[t] - m); s += e[t]; }
+        for (int t = 0; t < kSeq; t++) att[t] = e[t] / s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A; i += kAudioThreads) {
+        float acc = 0.0f;
+        for (int t = 0; t < kSeq; t++) acc += att[t] * codes[t * A + i];
+        enc[(size_t)win * A + i] = acc;
+    }
+}
+
+__global__ void k_audio_smooth(const float *__restrict__ enc, uint32_t n, uint32_t dim, float lambda, float *__restrict__ state,
+                               int state_valid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dim) return;
+    float s = state[i];
+    bool valid = state_valid != 0;
+    const float keep = lambda, take = (float)(1.0 - (double)lambda);  // Python: _lambda * a + (1 - _lambda) * b
+    for (uint32_t f = 0; f < n; f++) {
+        const float e = enc[(size_t)f * dim + i];
+        s = valid ? keep * s + take * e : e;
+        valid = true;
+    }
+    state[i] = s;
+}
+
+static int check_audio(const rn_audio_weights_t *w) {
+    RN_REQUIRE(w, "audio: null weights");
+    for (int l = 0; l < 4; l++) RN_REQUIRE(w->conv_w[l] && w->conv_b[l], "audio: null AudioNet conv weights");
+    RN_REQUIRE(w->fc_w[0] && w->fc_b[0] && w->fc_w[1] && w->fc_b[1], "audio: null AudioNet fc weights");
+    RN_REQUIRE(w->dim_in >= 1 && w->dim_in <= (uint32_t)kMaxDimIn && w->dim_aud >= 1 && w->dim_aud <= 64,
+               "audio: dim_in must be <= 64 and dim_aud <= 64 (got %u, %u)", w->dim_in, w->dim_aud);
+    if (w->has_att) {
+        for (int l = 0; l < 5; l++) RN_REQUIRE(w->att_conv_w[l] && w->att_conv_b[l], "audio: null AudioAttNet conv weights");
+        RN_REQUIRE(w->att_fc_w && w->att_fc_b, "audio: null AudioAttNet fc weights");
+    }
+    return RN_OK;
+}
+
+static AudioW audio_w(const rn_audio_weights_t *w) {
+    AudioW a{};
+    for (int l = 0; l < 4; l++) { a.conv_w[l] = w->conv_w[l]; a.conv_b[l] = w->conv_b[l]; }
+    for (int l = 0; l < 2; l++) { a.fc_w[l] = w->fc_w[l]; a.fc_b[l] = w->fc_b[l]; }
+    for (int l = 0; l < 5; l++) { a.att_conv_w[l] = w->att_conv_w[l]; a.att_conv_b[l] = w->att_conv_b[l]; }
+    a.att_fc_w = w->att_fc_w; a.att_fc_b = w->att_fc_b;
+    a.dim_in = w->dim_in; a.dim_aud = w->dim_aud; a.has_att = w->has_att ? 1u : 0u;
+    return a;
+}
+
+}  // namespace rn
+
+using namespace rn;
+
+extern "C" {
+
+int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    if (int rc = check_audio(w)) return rc;
+    RN_REQUIRE(auds && enc, "audio_encode_windows: null pointer");
+    hipLaunchKernelGGL(k_audio_encode, dim3(n), dim3(kAudioThreads), 0, as_stream(stream), audio_w(w), Source{auds, 0u, 0u, 0}, enc);
+    return check_launch("audio_encode_windows");
+}
+
+int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint32_t T, uint32_t first, uint32_t n,
+                           float *enc, rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    if (int rc = check_audio(w)) return rc;
+    RN_REQUIRE(feats && enc, "audio_encode_stream: null pointer");
+    RN_REQUIRE(w->has_att && T >= 8, "audio_encode_stream: needs the attention window (has_att) and a stream of >= 8 frames");
+    hipLaunchKernelGGL(k_audio_encode, dim3(n), dim3(kAudioThreads), 0, as_stream(stream), audio_w(w), Source{feats, T, first, 1}, enc);
+    return check_launch("audio_encode_stream");
+}
+
+int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,
+                    rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    RN_REQUIRE(enc && state && dim >= 1, "audio_smooth: null pointer");
+    hipLaunchKernelGGL(k_audio_smooth, dim3(div_up(dim, 64)), dim3(64), 0, as_stream(stream), enc, n, dim, lambda, state,
+                       state_valid);
+    return check_launch("audio_smooth");
+}
+
+}  // extern "C"

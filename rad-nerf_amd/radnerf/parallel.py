@@ -95,6 +95,13 @@ class FrameParallelRenderer(_Bookkeeping):
         if not frames or not m.smooth_lips:
             return
         n = self.scene.n_frames
+        feats = self.scene.aud_features
+        if (getattr(m, "fused_audio_enabled", None) is not None and self.scene.opt.att == 2 and n >= 8 and feats.is_cuda
+                and feats.dtype == torch.float32 and m.fused_audio_enabled()):
+            # fused engine: the codes of all skipped frames in ONE launch (windows cut on the device), then the recurrence
+            from . import audio
+            audio.smooth_(m, audio.encode_stream(m, feats, frames[0] % n, len(frames)))
+            return
         for g in frames:  # tiny networks; kept sequential so the arithmetic equals the reference's per-frame path
             enc = m.encode_audio(get_audio_features(self.scene.aud_features, self.scene.opt.att, g % n))
             m.enc_a = enc if m.enc_a is None else 0.35 * m.enc_a + (1 - 0.35) * enc
@@ -144,15 +151,20 @@ class TileParallelRenderer(_Bookkeeping):
     """BASELINE config 4 (a single 1024^2 frame over 8 GPUs).  `step(i)` renders this rank's rows of global frame i
     and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (identical on every rank)."""
 
-    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule="frame"):
+    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule=None):
         """schedule="frame": the ranks agree on the whole frame's step schedule (one 4-byte all-reduce per loop
-        iteration, enqueued on the device; fused engine) so the assembled image IS the whole-frame render;
-        schedule="band": no collective inside the loop, each band follows the reference's policy for its own rays."""
+        iteration, enqueued on the device; fused engine only) so the assembled image IS the whole-frame render;
+        schedule="band": no collective inside the loop, each band follows the reference's policy for its own rays.
+        Default: "frame" with the fused engine, "band" otherwise."""
         self.scene, self.rank, self.world, self.dist, self.band = scene, rank, world, dist, band
+        fused_engine = getattr(getattr(scene, "opt", None), "engine", "ops") == "fused"
+        if schedule is None:
+            schedule = "frame" if fused_engine else "band"
         if schedule == "frame" and dist is not None and world > 1:
-            if getattr(scene.opt, "engine", "ops") != "fused":
+            if not fused_engine:
                 raise RuntimeError("schedule='frame' needs the fused engine (device-resident loop state)")
             scene.model.shard_schedule = (dist, scene.H * scene.W)
+        self.schedule = schedule
         H, W = scene.H, scene.W
         self.rows = [stripe_rows(H, r, world, band) for r in range(world)]
         self.n_max = max(len(r) for r in self.rows)

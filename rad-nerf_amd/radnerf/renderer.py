@@ -99,6 +99,13 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _audio_code(self, auds):
         """encode_audio + the lip-smoothing EMA (nerf/renderer.py:188-194); stateful across frames."""
+        if self._fused_audio(auds):
+            # one kernel for AudioNet + AudioAttNet, one for the smoothing recurrence (radnerf/audio.py)
+            from . import audio
+            enc_a = audio.encode_windows(self, auds)
+            if self.smooth_lips:
+                enc_a = audio.smooth_(self, enc_a)
+            return enc_a
         enc_a = self.encode_audio(auds)
         if enc_a is not None and self.smooth_lips:
             if self.enc_a is not None:
@@ -106,6 +113,21 @@ class NeRFRenderer(nn.Module):
                 enc_a = _lambda * self.enc_a + (1 - _lambda) * enc_a
             self.enc_a = enc_a
         return enc_a
+
+    def fused_audio_enabled(self):
+        """The fused engine also takes the audio code off PyTorch (inference only; --emb ids and odd shapes stay torch)."""
+        if self.training or self.engine != "fused" or getattr(self.opt, "audio_engine", "fused") != "fused":
+            return False
+        ok = getattr(self, "_fused_audio_ok", None)
+        if ok is None:
+            from . import audio
+            ok = self._fused_audio_ok = audio.supported(self)
+        return ok
+
+    def _fused_audio(self, auds):
+        if auds is None or not self.fused_audio_enabled() or not auds.is_cuda or auds.dtype != torch.float32:
+            return False
+        return tuple(auds.shape) == (8 if self.att > 0 else 1, self.audio_in_dim, 16)
 
     def _march_loop_ops(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps,
                         T_thresh):
