@@ -149,7 +149,8 @@ int rn_blend_frame(float *image, const float *weights_sum, const float *bg, floa
  * NeRFNetwork.encode_audio (nerf/network.py:170-185) = AudioNet (nerf/network.py:41-67: 4 x Conv1d(k3, s2, p1) +
  * LeakyReLU(0.02) over the 16-sample window, Linear-LeakyReLU-Linear) on each of the 8 frames of the attention window,
  * then AudioAttNet (nerf/network.py:10-37: 5 x Conv1d(k3, s1, p1) + LeakyReLU(0.02) over the 8 codes, Linear(8,8),
- * softmax, weighted sum) -- ~45 tiny PyTorch launches per frame in the reference, ONE workgroup per window here.
+ * softmax, weighted sum) -- ~45 tiny PyTorch launches per frame in the reference; here one workgroup per (window, frame)
+ * for AudioNet and one per window for the attention: two launches for any number of windows.
  * All weights are the modules' own tensors (Conv1d [cout, cin, 3] + bias, Linear [out, in] + bias), fp32. */
 typedef struct {
     const float *conv_w[4], *conv_b[4];         /* audio_net.encoder_conv.{0,2,4,6}: dim_in->32->32->64->64 */
@@ -161,13 +162,15 @@ typedef struct {
 #define RN_AUDIO_SEQ 8   /* frames per attention window */
 #define RN_AUDIO_WIN 16  /* feature samples per frame */
 /* enc[i, :] = encode_audio(auds[i]) for n windows; auds: [n, (has_att ? 8 : 1), dim_in, 16] as NeRFRenderer.run_cuda
- * receives them (nerf/renderer.py:186). */
-int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, rn_stream_t stream);
+ * receives them (nerf/renderer.py:186).  workspace: n * 8 * dim_aud floats of scratch for the per-frame codes (caller-
+ * allocated like every buffer; may be NULL when has_att == 0). */
+int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, float *workspace,
+                            rn_stream_t stream);
 /* The same for n consecutive frames (first + i) mod T of a feature stream feats [T, dim_in, 16]: the windows are cut on
  * the device exactly as get_audio_features(att_mode=2) does (nerf/utils.py:56-72: frames index-4 .. index+3, zero rows
  * outside the stream).  Needs T >= 8 and has_att. */
 int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint32_t T, uint32_t first, uint32_t n,
-                           float *enc, rn_stream_t stream);
+                           float *enc, float *workspace, rn_stream_t stream);
 /* Lip smoothing (nerf/renderer.py:190-194) folded over n codes in order:
  * state = state_valid ? lambda * state + (1 - lambda) * enc[i] : enc[i]; state [dim] is updated in place. */
 int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,

@@ -2,10 +2,11 @@
 //
 // What is computed: NeRFNetwork.encode_audio (nerf/network.py:170-185) = AudioNet (:41-67) on the 8 frames of the
 // attention window + AudioAttNet (:10-37); then the lip-smoothing EMA of nerf/renderer.py:190-194 (rn_audio_smooth).
-// How: one 256-thread workgroup per window.  Activations live in LDS ([frame][channel][position]); each layer's
-// weights are staged into LDS with coalesced loads, then every thread produces outputs in a strided loop.  ~0.6 M MAC
-// per window: the point is latency (1 launch instead of ~45) -- which is also what lets a frame-parallel rank advance
-// the smoothing state through the frames other ranks render without paying 45 launches for each of them.
+// How: AudioNet is independent per frame, so k_audio_frames runs one 256-thread workgroup per (window, frame) -- 8 per
+// window -- and k_audio_attend one per window.  Activations live in LDS ([channel][position]); each layer's weights are
+// staged into LDS with coalesced loads, then every thread produces outputs in a strided loop.  ~0.6 M MAC per window:
+// the point is latency (2 launches instead of ~45) -- which is also what lets a frame-parallel rank advance the
+// smoothing state through the frames other ranks render without paying 45 launches for each of them.
 #include "rn_common.h"
 
 #include "../../include/radnerf_fused.h"
@@ -71,48 +72,53 @@ struct Source {
     int from_stream;
 };
 
-__global__ void __launch_bounds__(kAudioThreads) k_audio_encode(AudioW w, Source src, float *__restrict__ enc) {
+// AudioNet on ONE frame per workgroup: blockIdx.x = window * frames_per_window + t; codes [n * frames][dim_aud]
+__global__ void __launch_bounds__(kAudioThreads) k_audio_frames(AudioW w, Source src, float *__restrict__ codes) {
     __shared__ float wts[kMaxWeights];
-    __shared__ float bufA[kSeq * kMaxDimIn * kWin];  // ping
-    __shared__ float bufB[kSeq * 32 * 8];             // pong (largest: conv1 output)
-    __shared__ float codes[kSeq * 64];
+    __shared__ float bufA[kMaxDimIn * kWin];  // ping
+    __shared__ float bufB[32 * 8];            // pong (largest: conv1 output)
     const int frames = w.has_att ? kSeq : 1;
     const int cin0 = (int)w.dim_in, A = (int)w.dim_aud;
-    const uint32_t win = blockIdx.x;
+    const uint32_t win = blockIdx.x / frames, t = blockIdx.x % frames;
 
-    // the window's input maps: x[:, :, 8 - 8 : 8 + 8] of nerf/network.py:62-63 is the whole 16-sample frame
-    for (int i = threadIdx.x; i < frames * cin0 * kWin; i += kAudioThreads) {
+    // the frame's input map: x[:, :, 8 - 8 : 8 + 8] of nerf/network.py:62-63 is the whole 16-sample frame
+    for (int i = threadIdx.x; i < cin0 * kWin; i += kAudioThreads) {
         float v;
         if (src.from_stream) {
-            const int f = i / (cin0 * kWin), rest = i % (cin0 * kWin);
             const int centre = (int)((src.first + win) % src.T);
-            const int g = centre - 4 + f;  // frames index-4 .. index+3, zero outside the stream
-            v = (g >= 0 && g < (int)src.T) ? src.base[(size_t)g * cin0 * kWin + rest] : 0.0f;
+            const int g = centre - 4 + (int)t;  // frames index-4 .. index+3, zero outside the stream
+            v = (g >= 0 && g < (int)src.T) ? src.base[(size_t)g * cin0 * kWin + i] : 0.0f;
         } else {
-            v = src.base[(size_t)win * frames * cin0 * kWin + i];
+            v = src.base[(size_t)blockIdx.x * cin0 * kWin + i];
         }
         bufA[i] = v;
     }
     // AudioNet.encoder_conv: dim_in -> 32 -> 32 -> 64 -> 64, lengths 16 -> 8 -> 4 -> 2 -> 1
     stage(wts, w.conv_w[0], 32 * cin0 * 3);
-    conv3(bufA, bufB, wts, w.conv_b[0], frames, cin0, 32, 16, 2);
+    conv3(bufA, bufB, wts, w.conv_b[0], 1, cin0, 32, 16, 2);
     stage(wts, w.conv_w[1], 32 * 32 * 3);
-    conv3(bufB, bufA, wts, w.conv_b[1], frames, 32, 32, 8, 2);
+    conv3(bufB, bufA, wts, w.conv_b[1], 1, 32, 32, 8, 2);
     stage(wts, w.conv_w[2], 64 * 32 * 3);
-    conv3(bufA, bufB, wts, w.conv_b[2], frames, 32, 64, 4, 2);
+    conv3(bufA, bufB, wts, w.conv_b[2], 1, 32, 64, 4, 2);
     stage(wts, w.conv_w[3], 64 * 64 * 3);
-    conv3(bufB, bufA, wts, w.conv_b[3], frames, 64, 64, 2, 2);  // -> [frames][64][1]
+    conv3(bufB, bufA, wts, w.conv_b[3], 1, 64, 64, 2, 2);  // -> [64][1]
     // encoder_fc1: Linear(64, 64) + LeakyReLU, Linear(64, dim_aud)
     stage(wts, w.fc_w[0], 64 * 64);
-    linear(bufA, bufB, wts, w.fc_b[0], frames, 64, 64, true);
+    linear(bufA, bufB, wts, w.fc_b[0], 1, 64, 64, true);
     stage(wts, w.fc_w[1], A * 64);
-    linear(bufB, codes, wts, w.fc_b[1], frames, 64, A, false);
+    linear(bufB, codes + (size_t)blockIdx.x * A, wts, w.fc_b[1], 1, 64, A, false);
+}
+
+// AudioAttNet on one window per workgroup: codes [n][8][A] -> enc [n][A]
+__global__ void __launch_bounds__(kAudioThreads) k_audio_attend(AudioW w, const float *__restrict__ codes_all,
+                                                                float *__restrict__ enc) {
+    __shared__ float wts[64 * 16 * 3];
+    __shared__ float bufA[64 * kSeq], bufB[16 * kSeq], codes[kSeq * 64], att[kSeq];
+    const int A = (int)w.dim_aud;
+    const uint32_t win = blockIdx.x;
+    for (int i = threadIdx.x; i < kSeq * A; i += kAudioThreads) codes[i] = codes_all[(size_t)win * kSeq * A + i];
     __syncthreads();
-    if (!w.has_att) {
-        for (int i = threadIdx.x; i < A; i += kAudioThreads) enc[(size_t)win * A + i] = codes[i];
-        return;
-    }
-    // AudioAttNet: x [8, A] -> permute -> [A channels][8 positions]
+    // x [8, A] -> permute -> [A channels][8 positions]
     for (int i = threadIdx.x; i < A * kSeq; i += kAudioThreads) bufA[i] = codes[(i % kSeq) * A + i / kSeq];
     const int chans[6] = {A, 16, 8, 4, 2, 1};
     float *a = bufA, *b = bufB;
@@ -123,7 +129,6 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_encode(AudioW w, Source
     }
     __syncthreads();  // a: [1][8] scores
     // attentionNet: Linear(8, 8) + Softmax(dim=1), then sum_t y[t] * x[t, :]
-    __shared__ float att[kSeq];
     if (threadIdx.x < kSeq) {
         float acc = w.att_fc_b[threadIdx.x];
         for (int k = 0; k < kSeq; k++) acc += w.att_fc_w[threadIdx.x * kSeq + k] * a[k];
@@ -189,22 +194,34 @@ using namespace rn;
 
 extern "C" {
 
-int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, rn_stream_t stream) {
+static int launch_audio(const rn_audio_weights_t *w, const Source &src, uint32_t n, float *enc, float *workspace, hipStream_t s,
+                        const char *what) {
+    const AudioW a = audio_w(w);
+    if (!a.has_att) {  // one frame per window: the frame code is the result
+        hipLaunchKernelGGL(k_audio_frames, dim3(n), dim3(kAudioThreads), 0, s, a, src, enc);
+        return check_launch(what);
+    }
+    RN_REQUIRE(workspace, "%s: workspace of n * 8 * dim_aud floats is required", what);
+    hipLaunchKernelGGL(k_audio_frames, dim3(n * kSeq), dim3(kAudioThreads), 0, s, a, src, workspace);
+    hipLaunchKernelGGL(k_audio_attend, dim3(n), dim3(kAudioThreads), 0, s, a, workspace, enc);
+    return check_launch(what);
+}
+
+int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, float *workspace,
+                            rn_stream_t stream) {
     if (n == 0) return RN_OK;
     if (int rc = check_audio(w)) return rc;
     RN_REQUIRE(auds && enc, "audio_encode_windows: null pointer");
-    hipLaunchKernelGGL(k_audio_encode, dim3(n), dim3(kAudioThreads), 0, as_stream(stream), audio_w(w), Source{auds, 0u, 0u, 0}, enc);
-    return check_launch("audio_encode_windows");
+    return launch_audio(w, Source{auds, 0u, 0u, 0}, n, enc, workspace, as_stream(stream), "audio_encode_windows");
 }
 
 int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint32_t T, uint32_t first, uint32_t n,
-                           float *enc, rn_stream_t stream) {
+                           float *enc, float *workspace, rn_stream_t stream) {
     if (n == 0) return RN_OK;
     if (int rc = check_audio(w)) return rc;
     RN_REQUIRE(feats && enc, "audio_encode_stream: null pointer");
     RN_REQUIRE(w->has_att && T >= 8, "audio_encode_stream: needs the attention window (has_att) and a stream of >= 8 frames");
-    hipLaunchKernelGGL(k_audio_encode, dim3(n), dim3(kAudioThreads), 0, as_stream(stream), audio_w(w), Source{feats, T, first, 1}, enc);
-    return check_launch("audio_encode_stream");
+    return launch_audio(w, Source{feats, T, first, 1}, n, enc, workspace, as_stream(stream), "audio_encode_stream");
 }
 
 int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,

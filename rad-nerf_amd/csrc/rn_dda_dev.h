@@ -44,7 +44,37 @@ struct Dda {
         dt_min = fminf(dt_max, 2 * kSqrt3 / (float)max_steps);   // :387
     }
 
+    // occupancy-grid cell of the lattice point at parameter t (raymarching.cu:404-419); returns the bit index.
+    //
+    // :415-417 spell the cell coordinate as 0.5 * (double)(x * mip_rbound + 1) * (double)H, narrowed to float by
+    // clamp().  v = x * mip_rbound + 1 has 24 significant bits and H < 2^24, so the double product v * H / 2 is exact
+    // and its narrowing is the correctly rounded value of v * H / 2 -- which is what the single fp32 multiply
+    // v * (0.5f * H) returns (0.5 * H is exact).  Same bits, no fp64.  With one cascade the level is 0 for every point.
+    __device__ __forceinline__ uint32_t cell_of(float t, float &x, float &y, float &z, float &dt, float &mip_bound, int &nx,
+                                                int &ny, int &nz) const {
+        x = clampf(ox + t * dx, -bound, bound);
+        y = clampf(oy + t * dy, -bound, bound);
+        z = clampf(oz + t * dz, -bound, bound);
+        dt = clampf(t * dt_gamma, dt_min, dt_max);
+        int level = 0;
+        if (Cf > 1.0f) {  // wave-uniform
+            const int lp = mip_from_pos(x, y, z, Cf), ld = mip_from_dt(dt, Hf, Cf);
+            level = lp > ld ? lp : ld;
+        }
+        mip_bound = fminf(scalbnf(1.0f, level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        const float half_h = 0.5f * Hf, top = (float)(H - 1);
+        nx = (int)clampf((x * mip_rbound + 1) * half_h, 0.0f, top);
+        ny = (int)clampf((y * mip_rbound + 1) * half_h, 0.0f, top);
+        nz = (int)clampf((z * mip_rbound + 1) * half_h, 0.0f, top);
+        // :419 -- evaluated in float (H3 is a float in the reference)
+        return (uint32_t)((float)level * H3 + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    }
+
     // Walk from t, at most `limit` occupied steps.  EMIT writes samples to xyzs/dirs/deltas.
+    // (Measured on MI355X: the walk is bound by its own arithmetic, ~100 VALU ops per lattice point, not by the
+    // dependent bitfield loads -- fetching the occupancy of the next 4 / 8 / 16 lattice points together and replaying the
+    // decisions on a bit mask made k_head_march 10-17 % slower, so the loop keeps the reference's shape.)
     template <bool EMIT>
     __device__ __forceinline__ uint32_t walk(float &t_io, uint32_t limit, float *xyzs, float *dirs,
                                              float *deltas) const {
@@ -52,26 +82,10 @@ struct Dda {
         uint32_t step = 0;
         uint32_t guard = 0;  // not in the reference: bounds the walk on degenerate inputs (far = inf)
         while (t < far && step < limit && guard < (1u << 20)) {
-            const float x = clampf(ox + t * dx, -bound, bound);
-            const float y = clampf(oy + t * dy, -bound, bound);
-            const float z = clampf(oz + t * dz, -bound, bound);
-            const float dt = clampf(t * dt_gamma, dt_min, dt_max);
-
-            const int lp = mip_from_pos(x, y, z, Cf), ld = mip_from_dt(dt, Hf, Cf);
-            const int level = lp > ld ? lp : ld;
-            const float mip_bound = fminf(scalbnf(1.0f, level), bound);
-            const float mip_rbound = 1 / mip_bound;
-
-            // :415-417 -- the 0.5 literal makes the product double; clamp() narrows it to float.
-            const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-            const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-            const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-
-            // :419 -- evaluated in float (H3 is a float in the reference)
-            const uint32_t index = (uint32_t)((float)level * H3 + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-            const bool occ = grid[index >> 3] & (1u << (index & 7u));
-
-            if (occ) {
+            float x, y, z, dt, mip_bound;
+            int nx, ny, nz;
+            const uint32_t index = cell_of(t, x, y, z, dt, mip_bound, nx, ny, nz);
+            if (grid[index >> 3] & (1u << (index & 7u))) {
                 if (EMIT) {
                     xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
                     dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;

@@ -21,8 +21,8 @@ class AudioWeightsT(C.Structure):
 
 
 _SIGS = {
-    "rn_audio_encode_windows": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr],
-    "rn_audio_encode_stream": [C.POINTER(AudioWeightsT), _ptr, _u32, _u32, _u32, _ptr, _ptr],
+    "rn_audio_encode_windows": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, _ptr],
+    "rn_audio_encode_stream": [C.POINTER(AudioWeightsT), _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_audio_smooth": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr],
 }
 for _n, _a in _SIGS.items():
@@ -85,8 +85,9 @@ def encode_windows(model, auds):
         raise RuntimeError(f"audio windows must be [n, {frames}, {model.audio_in_dim}, 16], got {tuple(auds.shape)}")
     n = auds.shape[0]
     enc = torch.empty(n, model.audio_dim, dtype=torch.float32, device=auds.device)
+    ws = torch.empty(n * 8, model.audio_dim, dtype=torch.float32, device=auds.device)
     w, keep = _weights(model)
-    hip.call("rn_audio_encode_windows", C.byref(w), hip.ptr(auds), n, hip.ptr(enc), hip.stream())
+    hip.call("rn_audio_encode_windows", C.byref(w), hip.ptr(auds), n, hip.ptr(enc), hip.ptr(ws), hip.stream())
     return enc
 
 
@@ -95,8 +96,10 @@ def encode_stream(model, feats, first, n):
     feats = feats.contiguous().float()
     T = feats.shape[0]
     enc = torch.empty(n, model.audio_dim, dtype=torch.float32, device=feats.device)
+    ws = torch.empty(n * 8, model.audio_dim, dtype=torch.float32, device=feats.device)
     w, keep = _weights(model)
-    hip.call("rn_audio_encode_stream", C.byref(w), hip.ptr(feats), T, int(first) % T, int(n), hip.ptr(enc), hip.stream())
+    hip.call("rn_audio_encode_stream", C.byref(w), hip.ptr(feats), T, int(first) % T, int(n), hip.ptr(enc), hip.ptr(ws),
+             hip.stream())
     return enc
 
 
