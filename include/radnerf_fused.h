@@ -176,6 +176,14 @@ int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint
 int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,
                     rn_stream_t stream);
 
+/* ---- ray generation -----------------------------------------------------------------------
+ * get_rays for the full image (nerf/utils.py:249-333, N = -1 branch): pixel (row r, column c) -> ray r * W + c with
+ * centre (c + 0.5, r + 0.5); dir = normalize(((c + 0.5) - cx) / fx, ((r + 0.5) - cy) / fy, 1); rays_d = dir @ R^T,
+ * rays_o = pose[:3, 3].  ~12 PyTorch launches and two [N,3] round trips in the reference, one kernel here.
+ * pose: device pointer to a row-major [4,4] (or [3,4]: row stride 4) cam2world matrix. */
+int rn_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
+                float *rays_d, rn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

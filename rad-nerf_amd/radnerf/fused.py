@@ -61,6 +61,7 @@ _SIGS = {
     "rn_head_begin": [C.POINTER(HeadT), _ptr],
     "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, C.c_int, _ptr],
     "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
+    "rn_get_rays": [_ptr, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
     "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
                        _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -345,3 +346,14 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     if want_u8:
         results["image_u8"] = u8
     return results
+
+
+def get_rays(pose, intrinsics, H, W):
+    """Full-image rays of one cam2world pose [4,4] (or [1,4,4]) on the device: dict(rays_o, rays_d) of shape [1, H*W, 3]
+    (get_rays with N = -1, nerf/utils.py:249-333) in one launch."""
+    pose = pose.reshape(-1, 4)[:4].contiguous().float()
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    rays_o = torch.empty(1, H * W, 3, dtype=torch.float32, device=pose.device)
+    rays_d = torch.empty(1, H * W, 3, dtype=torch.float32, device=pose.device)
+    hip.call("rn_get_rays", hip.ptr(pose), fx, fy, cx, cy, int(H), int(W), hip.ptr(rays_o), hip.ptr(rays_d), hip.stream())
+    return {"rays_o": rays_o, "rays_d": rays_d}

@@ -124,7 +124,11 @@ class SyntheticScene:
         """Inputs of model.render for frame i (cached rays; everything resident on the device)."""
         i = i % self.n_frames
         if i not in self._rays:
-            r = get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
+            if self.device.type == "cuda" and getattr(self.opt, "engine", "ops") == "fused" and getattr(self.opt, "ray_engine", "fused") == "fused":
+                from . import fused                                   # one kernel (rn_get_rays) instead of ~12 torch launches
+                r = fused.get_rays(self.poses[i], self.intrinsics, self.H, self.W)
+            else:
+                r = get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
             self._rays[i] = (r["rays_o"].contiguous(), r["rays_d"].contiguous())
         rays_o, rays_d = self._rays[i]
         return dict(rays_o=rays_o, rays_d=rays_d, auds=get_audio_features(self.aud_features, self.opt.att, i),

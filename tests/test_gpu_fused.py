@@ -217,7 +217,7 @@ def test_hash_grid_fused_network_matches_oracle(po, hiplib):
 
 
 def test_fused_equals_ops_engine(hiplib):
-    a, b = _scene(96, "fused"), _scene(96, "ops")
+    a, b = _scene(96, "fused", ray_engine="torch"), _scene(96, "ops")     # same rays for both (rn_get_rays differs by 1 ulp)
     for i in range(2):
         with torch.no_grad():
             ia = a.render(i)["image"]
