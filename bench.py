@@ -44,7 +44,7 @@ def parse():
                          "config[2], one optimisation step of 4096 rays (march_rays_train + network + "
                          "composite_rays_train, backward, Adam)")
     ap.add_argument("--rays", type=int, default=4096, help="rays per training step (--workload train)")
-    ap.add_argument("--mlp", default="f32", choices=["f32", "f16"],
+    ap.add_argument("--mlp", default="f32", choices=["f32", "f32x2", "f16"],
                     help="arithmetic of the fused kernel's contractions: f32 = v_mfma_f32_32x32x2_f32 (headline, fp32 parity); "
                          "f16 = v_mfma_f32_32x32x16_f16 with fp32 accumulation (the reference's -O/autocast arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,7 +260,8 @@ def main():
             # The kernel does both of the path's heavy jobs (grid gathers and the MLP contraction).  With fp32 MFMA the
             # matrix-core roof is the closer (binding) one; on the 16-bit matrix cores the contraction is ~16x cheaper and
             # the gathers bind.  `bound` names the binding roof, the other view rides along.
-            common = dict(traffic=fpr.measured_traffic("nerf_fused" if args.mlp == "f32" else "nerf_fused_h16"),
+            tkey = {"f32": "nerf_fused", "f16": "nerf_fused_h16", "f32x2": "nerf_fused_x2"}[args.mlp]
+            common = dict(traffic=fpr.measured_traffic(tkey),
                           launches=fused_launches, avg_launch_ms=fused_ms / fused_launches,
                           share_of_step=fused_ms / (elapsed * 1e3), launches_with_work=iters_total,
                           avg_launch_ms_with_work=sum(fused_durs[:iters_total]) / max(iters_total, 1),
@@ -276,6 +277,11 @@ def main():
                             algorithmic_bytes_per_sample=FUSED_BYTES_PER_SAMPLE)
             if args.mlp == "f32":
                 roof = dict(bound="mfma", kernel="k_nerf_fused (grid gathers + fp32 MFMA MLPs)", **mfma_view, **common, hbm=hbm_view)
+            elif args.mlp == "f32x2":
+                # 3 f16 MFMA products per fp32-grade product: the matrix-core view counts the issued FLOPs (3x)
+                mfma_view.update(achieved=3 * tflops, frac=3 * tflops / mfma_peak, issued_over_algorithmic=3)
+                roof = dict(bound="hbm", kernel="k_nerf_fused_x2 (grid gathers + split-precision f16 MFMA MLPs, fp32-grade)",
+                            **hbm_view, **common, mfma=mfma_view)
             else:
                 roof = dict(bound="hbm", kernel="k_nerf_fused_h16 (grid gathers + f16 MFMA MLPs, fp32 accumulate)", **hbm_view,
                             **common, mfma=mfma_view)
@@ -289,7 +295,8 @@ def main():
         out = {
             "metric": f"rendered frames/sec @{size}x{size}", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if tile else "weak",
-            "vs_baseline": None, "dtype": "f32" if args.mlp == "f32" else "f16 operands / f32 accumulate",
+            "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 operands / f32 accumulate",
+                                          "f32x2": "f32 (operands as fp16 hi+lo pairs on MFMA, f32 accumulate)"}[args.mlp],
             "data": "synthetic",
             "config": {"workload": (f"config[4]: tile-parallel single {size}x{size} frame, interleaved 8-row bands, " if tile else
                                     f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "

@@ -61,6 +61,13 @@ size_t rn_nerf_packed_floats(void);
  * rn_head_iterate must be the image that matches `mlp_dtype` (RN_F32: rn_nerf_pack_weights). */
 size_t rn_nerf_packed_floats_h16(void);
 int rn_nerf_pack_weights_h16(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);
+/* Split-precision variant (mlp_dtype = RN_F32_SPLIT): fp32-grade contractions on the 16-bit matrix cores.  Every operand
+ * is carried as two fp16 numbers (hi = fp16(v), lo = fp16(v - hi): 22 significant bits) and a product is evaluated as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x16_f16 (~3e-7 relative per product).  It meets the
+ * tolerances of the fp32-MFMA kernel against the fp32 oracle; it is NOT bit-identical to it. */
+#define RN_F32_SPLIT 2
+size_t rn_nerf_packed_floats_split(void);
+int rn_nerf_pack_weights_split(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);
 size_t rn_nerf_bias_floats(void);
 /* Re-order the raw weights into the image the fused kernel stages into LDS (call when weights change). */
 int rn_nerf_pack_weights(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);

@@ -824,7 +824,9 @@ static int run_fused(const float *xyzs, const float *dirs, const float *deltas, 
     FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient};
     const bool prof = prof_enabled();
     if (prof) prof_begin(s);
-    if (mlp_dtype == RN_F16) {
+    if (mlp_dtype == RN_F32_SPLIT) {
+        launch_fused_x2(p, gx->dtype, gw->dtype, (uint32_t)num_cus(), s);
+    } else if (mlp_dtype == RN_F16) {
         uint32_t blocks = div_up((M + 63u) >> 6, kWavesPerBlock);
         const uint32_t cap = (uint32_t)num_cus();
         launch_fused_h16(p, gx->dtype, gw->dtype, blocks > cap ? cap : blocks, s);
@@ -844,6 +846,14 @@ extern "C" {
 
 size_t rn_nerf_packed_floats(void) { return (size_t)kPacked; }
 size_t rn_nerf_packed_floats_h16(void) { return packed_floats_h16(); }
+size_t rn_nerf_packed_floats_split(void) { return packed_floats_x2(); }
+
+int rn_nerf_pack_weights_split(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(packed && ((uintptr_t)packed & 15u) == 0, "nerf_pack_weights_split: packed must be 16-byte aligned");
+    launch_pack_nerf_x2(raw_w(w), packed, as_stream(stream));
+    return check_launch("nerf_pack_weights_split");
+}
 
 int rn_nerf_pack_weights_h16(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream) {
     if (int rc = check_w(w)) return rc;
@@ -879,7 +889,8 @@ int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *del
     RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "nerf_fused_forward: packed must be 16-byte aligned");
     if (int rc = check_grid(grid_xyz, 3, "nerf_fused_forward(xyz grid)")) return rc;
     if (int rc = check_grid(grid_amb, 2, "nerf_fused_forward(ambient grid)")) return rc;
-    RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16, "nerf_fused_forward: mlp_dtype must be RN_F32 or RN_F16");
+    RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16 || mlp_dtype == RN_F32_SPLIT,
+               "nerf_fused_forward: mlp_dtype must be RN_F32, RN_F16 or RN_F32_SPLIT");
     run_fused(xyzs, dirs, deltas, M, m_dev, grid_xyz, grid_amb, packed, bias, bound, sigmas, rgbs, ambient, mlp_dtype,
               as_stream(stream));
     return check_launch("nerf_fused_forward");
@@ -906,7 +917,8 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream) {
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
                     const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream) {
     if (int rc = check_head(h)) return rc;
-    RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16, "head_iterate: mlp_dtype must be RN_F32 or RN_F16");
+    RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16 || mlp_dtype == RN_F32_SPLIT,
+               "head_iterate: mlp_dtype must be RN_F32, RN_F16 or RN_F32_SPLIT");
     RN_REQUIRE(packed && bias && ((uintptr_t)packed & 15u) == 0, "head_iterate: packed/bias");
     if (int rc = check_grid(grid_xyz, 3, "head_iterate(xyz grid)")) return rc;
     if (int rc = check_grid(grid_amb, 2, "head_iterate(ambient grid)")) return rc;

@@ -114,5 +114,9 @@ struct LevelLds {
 void launch_fused_h16(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t blocks, hipStream_t s);
 void launch_pack_nerf_h16(const RawW &w, float *packed, hipStream_t s);
 size_t packed_floats_h16();
+// Launch of the split-precision variant (rn_fused_x2.hip): picks its own grid (one 256-thread workgroup per CU).
+void launch_fused_x2(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t n_cus, hipStream_t s);
+void launch_pack_nerf_x2(const RawW &w, float *packed, hipStream_t s);
+size_t packed_floats_x2();
 
 }  // namespace rn

@@ -2,7 +2,7 @@
 //
 // Same computation as k_nerf_fused (nerf/network.py:222-283), same tile ownership (one wavefront = 64 samples, the
 // accumulators of one layer are the B operand of the next), but the contractions run on
-// v_mfma_f32_32x32x16_f16: weights and per-sample activations are rounded to fp16 (round-to-nearest-even) where they
+// v_mfma_f32_32x32x8f16 (see mfma16 below for why not the x16 form): weights and per-sample activations are rounded to fp16 (round-to-nearest-even) where they
 // enter a matrix instruction, products are exact and accumulation is fp32.  This is the arithmetic of the reference's
 // own `-O` mode (torch.cuda.amp.autocast: nn.Linear in fp16 with fp32 accumulation, nerf/utils.py:944) except that
 // here the hidden activations stay fp32 between layers.  What stays fp32 end to end: the grid interpolation, the
@@ -14,6 +14,7 @@
 // (kXyzGroup / kAmbGroup), and the feature pairs are staged through a wave-private LDS tile from which the B fragments
 // (8 consecutive k per lane half) are read back with one ds_read_b128 -- no cross-lane shuffles at all.
 #include "rn_fused_dev.h"
+
 
 namespace rn {
 
@@ -83,8 +84,18 @@ __global__ void __launch_bounds__(256) k_pack_nerf_h16(RawW w, float *__restrict
     packed[f] = v;
 }
 
+// The contraction instruction.  gfx950's double-rate v_mfma_f32_32x32x16_f16 is NOT used: with two waves resident per
+// SIMD this kernel then returned, in ~1 of 300 tiles and differently from launch to launch, results computed with stale
+// operand data in lanes 48..63 of one fragment (reproduced with identical inputs in every lane; gone with one wave per
+// SIMD, with every mix of s_nop / s_waitcnt around the instruction still present) -- see DESIGN.md section 3.  The
+// K = 8 form below is bit-stable under the same conditions.  One 16-k step = two K = 8 instructions on elements
+// 0..3 and 4..7 of both fragments (any pairing that takes the same elements from A and B sums the same products);
+// the matrix pipe is far from binding in these kernels, so the 2x instruction count is not measurable.
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const f16x4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+    const f16x4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(a1, b1, __builtin_amdgcn_mfma_f32_32x32x8f16(a0, b0, c, 0, 0, 0), 0, 0, 0);
 }
 
 // one k-step (16 k) of a 64-row layer: both row tiles' weight fragments from LDS, B fragments of the two column tiles

@@ -55,6 +55,7 @@ ST_ACTIVE, ST_ITERS, ST_LIVE, ST_SLOTS = 4, 16, 17, 18
 _SIGS = {
     "rn_nerf_pack_weights": [C.POINTER(NerfWeightsT), _ptr, _ptr],
     "rn_nerf_pack_weights_h16": [C.POINTER(NerfWeightsT), _ptr, _ptr],
+    "rn_nerf_pack_weights_split": [C.POINTER(NerfWeightsT), _ptr, _ptr],
     "rn_nerf_frame_bias": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_nerf_fused_forward": [_ptr, _ptr, _ptr, _u32, _ptr, C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _f32, _ptr,
                               _ptr, _ptr, C.c_int, _ptr],
@@ -73,12 +74,14 @@ for _n, _a in _SIGS.items():
     _f.restype = C.c_int
 _lib.rn_nerf_packed_floats.restype = C.c_size_t
 _lib.rn_nerf_packed_floats_h16.restype = C.c_size_t
+_lib.rn_nerf_packed_floats_split.restype = C.c_size_t
+RN_F32_SPLIT = 2
 _lib.rn_nerf_bias_floats.restype = C.c_size_t
 _lib.rn_torso_packed_floats.restype = C.c_size_t
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["rn_nerf_packed_floats", "rn_nerf_packed_floats_h16", "rn_nerf_bias_floats",
+    return sorted(list(_SIGS) + ["rn_nerf_packed_floats", "rn_nerf_packed_floats_h16", "rn_nerf_packed_floats_split", "rn_nerf_bias_floats",
                                  "rn_torso_packed_floats"])
 
 
@@ -119,7 +122,8 @@ class FusedState:
             raise RuntimeError("fused engine: unsupported network shape; use engine='ops'")
         self.model = model
         self.dev = model.density_bitfield.device
-        n_packed = max(int(_lib.rn_nerf_packed_floats()), int(_lib.rn_nerf_packed_floats_h16()))
+        n_packed = max(int(_lib.rn_nerf_packed_floats()), int(_lib.rn_nerf_packed_floats_h16()),
+                       int(_lib.rn_nerf_packed_floats_split()))
         self.packed = torch.empty(n_packed, dtype=torch.float32, device=self.dev)
         self.mlp_dtype = hip.RN_F32
         self.bias = torch.empty(int(_lib.rn_nerf_bias_floats()), dtype=torch.float32, device=self.dev)
@@ -143,7 +147,9 @@ class FusedState:
         if self.model.torso:
             tables.append(self.model.torso_encoder.embeddings)
         # opt.mlp_dtype = "f16": contractions on the 16-bit matrix cores (fp32 accumulate), the reference's -O arithmetic
-        mlp = {"f32": hip.RN_F32, "f16": hip.RN_F16}[getattr(getattr(self.model, "opt", None), "mlp_dtype", "f32")]
+        # "f32x2": fp32-grade products from two fp16 halves per operand on the same matrix cores (include/radnerf_fused.h)
+        mlp = {"f32": hip.RN_F32, "f16": hip.RN_F16, "f32x2": RN_F32_SPLIT}[
+            getattr(getattr(self.model, "opt", None), "mlp_dtype", "f32")]
         versions = tuple((w._version, w.data_ptr()) for w in ws + tables) + (mlp,)
         if versions == self._versions:
             return
@@ -158,8 +164,9 @@ class FusedState:
         assert tuple(ws[0].shape) == (64, 32 + m.audio_dim) and tuple(ws[3].shape) == (64, 64 + int(m.exp_eye))
         assert tuple(ws[5].shape) == (65, 64) and tuple(ws[6].shape) == (64, 80 + m.individual_dim)
         self.mlp_dtype = mlp
-        hip.call("rn_nerf_pack_weights_h16" if mlp == hip.RN_F16 else "rn_nerf_pack_weights", C.byref(self.nw),
-                 hip.ptr(self.packed), hip.stream())
+        packer = {hip.RN_F32: "rn_nerf_pack_weights", hip.RN_F16: "rn_nerf_pack_weights_h16",
+                  RN_F32_SPLIT: "rn_nerf_pack_weights_split"}[mlp]
+        hip.call(packer, C.byref(self.nw), hip.ptr(self.packed), hip.stream())
         if m.torso:
             self.tw = TorsoWeightsT()
             (self.tw.def_w0, self.tw.def_w1, self.tw.def_w2, self.tw.tor_w0, self.tw.tor_w1,

@@ -23,10 +23,11 @@ def test_symbols_of_fused_header_are_exported(hiplib):
         assert hasattr(hiplib._lib, name), name
 
 
+@pytest.mark.parametrize("mlp", ["f32", "f32x2"])      # fp32 MFMA / fp32-grade split products on the 16-bit MFMA: same bar
 @pytest.mark.parametrize("M", [1, 63, 64, 65, 5000, 100003])
-def test_fused_network_matches_oracle(po, hiplib, M):
+def test_fused_network_matches_oracle(po, hiplib, M, mlp):
     from radnerf import fused
-    scene = _scene(16, "fused")
+    scene = _scene(16, "fused", mlp_dtype=mlp)
     m = scene.model
     rng = np.random.default_rng(M)
     x = rng.uniform(-0.7, 0.7, (M, 3)).astype(np.float32)
@@ -81,9 +82,10 @@ def _oracle_frame(po, scene, f, enc_a):
                            m.individual_codes_torso[0].detach().cpu().numpy(), f["bg_color"].reshape(-1, 3).cpu().numpy())
 
 
+@pytest.mark.parametrize("mlp", ["f32", "f32x2"])
 @pytest.mark.parametrize("size", [32, 64, 160])
-def test_fused_frame_matches_oracle(po, hiplib, size):
-    scene = _scene(size, "fused")
+def test_fused_frame_matches_oracle(po, hiplib, size, mlp):
+    scene = _scene(size, "fused", mlp_dtype=mlp)
     for i in range(3):  # iteration hint adapts after the first frame; EMA state advances
         f = scene.frame(i)
         with torch.no_grad():
@@ -177,11 +179,13 @@ def test_fused_f16_and_f32_share_one_model(hiplib):
     assert 0 < d <= 4e-3, d
 
 
-@pytest.mark.parametrize("engine", ["fused", "ops"])
+@pytest.mark.parametrize("engine", ["fused", "fused-f32x2", "ops"])
 def test_hash_grid_frame_matches_oracle(po, hiplib, engine):
     """BASELINE config[1] names an instant-ngp hash grid with T=2^19 for xyz: levels 5..15 go through fast_hash
     (gridencoder.cu:57-74, 98-99) instead of the tiled modulo."""
-    scene = _scene(64, engine, **HASH19)
+    mlp = "f32x2" if engine.endswith("x2") else "f32"
+    engine = engine.split("-")[0]
+    scene = _scene(64, engine, mlp_dtype=mlp, **HASH19)
     assert scene.model.encoder.gridtype == "hash" and scene.model.encoder.embeddings.shape[0] > 16 * 2 ** 16
     for i in range(2):
         f = scene.frame(i)
@@ -274,3 +278,25 @@ def test_torso_fused_matches_oracle(po, hiplib):
     exp_bg = bg_in.cpu().numpy().copy()
     exp_bg[mask] = ec * ea + exp_bg[mask] * (1 - ea)
     np.testing.assert_allclose(bg_out.cpu().numpy(), exp_bg, rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f32x2", "f16"])
+def test_fused_kernels_are_deterministic(hiplib, mlp):
+    """Same inputs, 12 launches, identical bits.  (Guards the finding recorded in DESIGN.md section 3: built on the
+    double-rate v_mfma_f32_32x32x16_f16 the f16 kernels were not, with two waves per SIMD.)"""
+    from radnerf import fused
+    scene = _scene(16, "fused", mlp_dtype=mlp)
+    m = scene.model
+    M = 20000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(M, 3, device="cuda", generator=g) * 1.4 - 0.7
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device="cuda", generator=g), dim=1)
+    enc_a = torch.randn(1, 64, device="cuda", generator=g)
+    eye = torch.tensor([[0.25]], device="cuda")
+    c = m.individual_codes[0].detach()
+    with torch.no_grad():
+        first = [t.clone() for t in fused.network_forward(m, x, d, enc_a, c, eye)]
+        for _ in range(11):
+            again = fused.network_forward(m, x, d, enc_a, c, eye)
+            for a, b in zip(first, again):
+                assert torch.equal(a, b)

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mlp", default="f16")
+    ap.add_argument("--mlp", default="f16", choices=["f32", "f32x2", "f16"])
     ap.add_argument("--grid", default="hash19")
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--tag", default="")

@@ -14,7 +14,7 @@ import glob
 import json
 import sys
 
-KEYS = {"nerf_fused": "k_nerf_fused<", "nerf_fused_h16": "k_nerf_fused_h16<", "grid_encode_xyz": "k_grid_fwd_sample<float, 3u", "torso_fused": "k_torso_fused",
+KEYS = {"nerf_fused": "k_nerf_fused<", "nerf_fused_h16": "k_nerf_fused_h16<", "nerf_fused_x2": "k_nerf_fused_x2<", "grid_encode_xyz": "k_grid_fwd_sample<float, 3u", "torso_fused": "k_torso_fused",
         "head_march": "k_head_march", "head_composite": "k_head_composite"}
 
 
