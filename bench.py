@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--mlp", default="f32", choices=["f32", "f32x2", "f16"],
                     help="arithmetic of the fused kernel's contractions: f32 = v_mfma_f32_32x32x2_f32 (headline, fp32 parity); "
                          "f16 = v_mfma_f32_32x32x16_f16 with fp32 accumulation (the reference's -O/autocast arithmetic)")
+    ap.add_argument("--no-loop-hint", action="store_true",
+                    help="enqueue all max_steps loop iterations per frame instead of (iterations seen in the warm-up + 2); "
+                         "with the hint the device flags any frame it was too small for and the run is repeated without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -206,7 +209,8 @@ def main():
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
                            opt=default_opt(engine=engine, mlp_dtype=args.mlp, **GRIDS[args.grid]))
     tile = args.workload == "tile"
-    fpr = (TileParallelRenderer if tile else FrameParallelRenderer)(scene, rank, world, dist)
+    fpr = (TileParallelRenderer(scene, rank, world, dist) if tile else
+           FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint))
 
     def barrier():
         if dist is not None:
@@ -223,13 +227,30 @@ def main():
         if engine == "fused":
             hip.prof_enable(True)
             c0 = fpr.loop_counters() or [0, 0, 0]
-        barrier()
-        t0 = time.perf_counter()
-        for s in range(W, W + K):
-            fpr.step(s)
-        fpr.finish()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        from radnerf.parallel import LoopHintTooSmall
+        for attempt in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            short = 0
+            try:
+                for s in range(W, W + K):
+                    fpr.step(s)
+                fpr.finish()
+            except LoopHintTooSmall:        # the device flagged a frame: this timing is void, repeat with every iteration
+                short = 1
+            barrier()
+            elapsed = time.perf_counter() - t0
+            flag = torch.tensor([short], dtype=torch.int32, device=device)
+            if dist is not None:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) == 0:
+                break
+            fpr.speculate_loop = False
+            from radnerf import fused as _fused
+            _fused.set_loop_hint(scene.model, None)
+            if engine == "fused":
+                hip.prof_collect(); hip.prof_durations()      # drop the void attempt's kernel timings
+                c0 = fpr.loop_counters() or [0, 0, 0]
         hip.set_timer(None)
         if engine == "fused":
             fused_launches, fused_ms = hip.prof_collect()
@@ -302,6 +323,8 @@ def main():
                                     f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "
                                    "max 16 steps/ray, 25 FPS pose stream, torso pass on",
                        "grid": args.grid, "engine": engine, "frames_per_gpu": K,
+                       "loop_iterations_enqueued": (getattr(getattr(scene.model, "_fused_state", None), "loop_hint", None)
+                                                    or scene.opt.max_steps),
                        "parallelism": f"{'tile' if tile else 'frame'}-parallel x{world}"},
             # tile-parallel: rank 0 counts its own band's samples; the bands are interleaved, so x world is the frame's
             "samples_per_s": live_pf * (world if tile else 1) * fps, "samples_per_frame": live_pf * (world if tile else 1),

@@ -129,6 +129,13 @@ int rn_head_reschedule(const rn_head_t *h, uint32_t iter_done, uint32_t schedule
 #define RN_HEAD_ST_ITERS 16      /* iterations that did work */
 #define RN_HEAD_ST_LIVE 17       /* live samples evaluated */
 #define RN_HEAD_ST_SLOTS 18      /* sample slots n_alive * n_step summed over iterations */
+#define RN_HEAD_ST_UNFINISHED 19 /* frames whose loop was still active when rn_head_check_done looked (see below) */
+/* Speculative loop length.  A caller that knows how many iterations frames of this stream need (device counters of
+ * earlier frames) may enqueue fewer than max_steps iterations and skip the no-op launches behind them; this entry point
+ * then records, on the device, whether the loop really was over after iteration iters_done - 1: if it was not,
+ * state[RN_HEAD_ST_UNFINISHED] is incremented and the caller must render that frame again with more iterations (the
+ * count is checked whenever the caller synchronises anyway).  Never needed when all max_steps iterations are enqueued. */
+int rn_head_check_done(const rn_head_t *h, uint32_t iters_done, rn_stream_t stream);
 
 /* ---- torso + blend ----------------------------------------------------------------------------------- */
 typedef struct {

@@ -494,6 +494,11 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
         next_state(st_next, N, offset + total, (uint32_t)st[1] + (uint32_t)st[2], max_steps);
 }
 
+// Was the loop over after the iterations the caller enqueued?  (`st` = the state bank the NEXT iteration would read.)
+__global__ void k_head_check_done(const int32_t *__restrict__ st, int32_t *__restrict__ unfinished) {
+    if (threadIdx.x == 0 && st[4]) atomicAdd(unfinished, 1);
+}
+
 // Whole-frame step schedule for a shard of the frame (see radnerf_fused.h): same policy as next_state, fed with the
 // frame-wide ray and live counts.
 __global__ void k_head_reschedule(int32_t *__restrict__ st, uint32_t schedule_N, const int32_t *__restrict__ alive_total) {
@@ -939,6 +944,13 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
                            h->block_counts);
     }
     return check_launch("head_iterate");
+}
+
+int rn_head_check_done(const rn_head_t *h, uint32_t iters_done, rn_stream_t stream) {
+    if (int rc = check_head(h)) return rc;
+    hipLaunchKernelGGL(k_head_check_done, dim3(1), dim3(64), 0, as_stream(stream), h->state + (iters_done & 1u) * 8,
+                       h->state + RN_HEAD_ST_UNFINISHED);
+    return check_launch("head_check_done");
 }
 
 int rn_head_reschedule(const rn_head_t *h, uint32_t iter_done, uint32_t schedule_N, const int32_t *alive_total,

@@ -50,6 +50,7 @@ class HeadT(C.Structure):
 
 
 RN_HEAD_STATE_INTS = 32
+ST_UNFINISHED = 19
 ST_ACTIVE, ST_ITERS, ST_LIVE, ST_SLOTS = 4, 16, 17, 18
 
 _SIGS = {
@@ -62,6 +63,7 @@ _SIGS = {
     "rn_head_begin": [C.POINTER(HeadT), _ptr],
     "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, C.c_int, _ptr],
     "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
+    "rn_head_check_done": [C.POINTER(HeadT), _u32, _ptr],
     "rn_get_rays": [_ptr, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
     "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
@@ -126,6 +128,7 @@ class FusedState:
                        int(_lib.rn_nerf_packed_floats_split()))
         self.packed = torch.empty(n_packed, dtype=torch.float32, device=self.dev)
         self.mlp_dtype = hip.RN_F32
+        self.loop_hint = None
         self.bias = torch.empty(int(_lib.rn_nerf_bias_floats()), dtype=torch.float32, device=self.dev)
         self.tpacked = (torch.empty(int(_lib.rn_torso_packed_floats()), dtype=torch.float32, device=self.dev)
                         if model.torso else None)
@@ -238,6 +241,21 @@ def loop_counters(model):
     return st.state[ST_ITERS:ST_SLOTS + 1].cpu().tolist()
 
 
+def unfinished_frames(model):
+    """Frames (cumulative) whose loop was cut short by a speculative iteration count (set_loop_hint); synchronises."""
+    st = getattr(model, "_fused_state", None)
+    if st is None or st._N == 0:
+        return 0
+    return int(st.state[ST_UNFINISHED].item())
+
+
+def set_loop_hint(model, iterations):
+    """Enqueue only `iterations` loop iterations per frame from now on (None: all max_steps, the default).  The device
+    records frames for which that was not enough (unfinished_frames); the caller checks it where it synchronises and
+    renders those frames again.  Meant for streams whose iteration count is known from earlier frames."""
+    _state(model).loop_hint = None if iterations is None else max(1, int(iterations))
+
+
 def _state(model):
     st = getattr(model, "_fused_state", None)
     if st is None or st.model is not model:
@@ -306,8 +324,11 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     hip.call("rn_head_begin", C.byref(h), s)
     shard = getattr(model, "shard_schedule", None)
     if shard is None:
+        n_iters = int(max_steps) if st.loop_hint is None else min(int(max_steps), st.loop_hint)
         hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0,
-                 int(max_steps), st.mlp_dtype, s)
+                 n_iters, st.mlp_dtype, s)
+        if n_iters < int(max_steps):
+            hip.call("rn_head_check_done", C.byref(h), n_iters, s)
     else:
         # This call renders a shard of a frame (tile-parallel): the step schedule must be the whole frame's, so the
         # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.

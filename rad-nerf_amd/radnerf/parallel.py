@@ -81,12 +81,23 @@ class _Bookkeeping:
 
 
 
+class LoopHintTooSmall(RuntimeError):
+    """A batch rendered with a speculative loop length contained frames that needed more iterations."""
+
+
 class FrameParallelRenderer(_Bookkeeping):
-    def __init__(self, scene, rank=0, world=1, dist=None, gather=True):
+    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False):
+        """speculate_loop (fused engine): after the first finish() the renderer knows how many loop iterations the
+        stream's frames take (device counters) and enqueues that many + 2 per frame instead of max_steps, skipping
+        the no-op launches behind them; the device flags any frame for which that was not enough and finish() raises
+        LoopHintTooSmall so the caller can render the batch again (never observed on a continuous pose stream)."""
         self.scene, self.rank, self.world, self.dist = scene, rank, world, dist
         self.gather = gather and dist is not None and world > 1
         self.pending = []
         self.frames_u8 = None
+        self.speculate_loop = speculate_loop and getattr(scene.opt, "engine", "ops") == "fused"
+        self._frames_since_finish = 0
+        self._counters = None
 
     # -- audio state ------------------------------------------------------------------------------
     def _advance_audio(self, frames):
@@ -124,7 +135,24 @@ class FrameParallelRenderer(_Bookkeeping):
                 work = self.dist.all_gather(list(buf.unbind(0)), u8.contiguous(), async_op=True)
             self.pending.append((work, buf, u8))
         self.last_frame = u8
+        self._frames_since_finish += 1
         return u8
+
+    def _update_loop_hint(self):
+        from . import fused
+        m = self.scene.model
+        cur = fused.loop_counters(m)                # synchronises; finish() is a synchronisation point anyway
+        unfinished = fused.unfinished_frames(m)
+        prev, self._counters = self._counters, (cur, unfinished)
+        if cur is None or not self._frames_since_finish:
+            return
+        if prev is not None and unfinished != prev[1]:
+            fused.set_loop_hint(m, None)
+            self._frames_since_finish = 0
+            raise LoopHintTooSmall(f"{unfinished - prev[1]} frame(s) needed more loop iterations than the hint")
+        iters = ((cur[0] - (prev[0][0] if prev else 0)) & 0xFFFFFFFF) / self._frames_since_finish
+        fused.set_loop_hint(m, int(-(-iters // 1)) + 2)
+        self._frames_since_finish = 0
 
     def _render_for_count(self, step):
         self.scene.render(frame_of(step, self.rank, self.world))
@@ -138,6 +166,8 @@ class FrameParallelRenderer(_Bookkeeping):
         if done:
             self.frames_u8 = done[-1]
         self.pending = []
+        if self.speculate_loop:
+            self._update_loop_hint()
         return done
 
 

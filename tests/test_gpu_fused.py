@@ -300,3 +300,46 @@ def test_fused_kernels_are_deterministic(hiplib, mlp):
             again = fused.network_forward(m, x, d, enc_a, c, eye)
             for a, b in zip(first, again):
                 assert torch.equal(a, b)
+
+
+def test_speculative_loop_length_is_flagged_when_too_small(po, hiplib):
+    """set_loop_hint: frames rendered with enough iterations equal the full loop and are not flagged; a hint that is
+    too small is flagged on the device (rn_head_check_done) so the caller can render again."""
+    from radnerf import fused
+    a, b = _scene(64, "fused"), _scene(64, "fused")
+    with torch.no_grad():
+        full = a.render(0)["image"].clone()
+        need = a.model.last_stats["iterations"]
+        b.render(1)                                   # creates the state
+        b.model.enc_a = None
+        fused.set_loop_hint(b.model, need + 1)
+        b.model.enc_a = None
+        again = _scene(64, "fused")
+        fused._state(again.model)
+        fused.set_loop_hint(again.model, need + 1)
+        img = again.render(0)["image"]
+        assert torch.equal(img, full) and fused.unfinished_frames(again.model) == 0
+        fused.set_loop_hint(again.model, max(1, need - 2))
+        again.model.enc_a = None
+        again.render(0)
+        assert fused.unfinished_frames(again.model) == 1
+        fused.set_loop_hint(again.model, None)
+        again.model.enc_a = None
+        assert torch.equal(again.render(0)["image"], full) and fused.unfinished_frames(again.model) == 1
+
+
+def test_frame_parallel_renderer_learns_the_loop_length(hiplib):
+    from radnerf import fused
+    from radnerf.parallel import FrameParallelRenderer
+    ref, spec = _scene(64, "fused"), _scene(64, "fused")
+    with torch.no_grad():
+        want = [ref.render(i)["image"].clone() for i in range(6)]
+        fpr = FrameParallelRenderer(spec, 0, 1, None, gather=False, speculate_loop=True)
+        got = [fpr.step(i) for i in range(3)]
+        fpr.finish()
+        hint = fused._state(spec.model).loop_hint
+        assert hint is not None and hint < spec.opt.max_steps
+        got += [fpr.step(i) for i in range(3, 6)]
+        fpr.finish()                                   # would raise LoopHintTooSmall
+    for g, w in zip(got, want):
+        assert torch.equal(g, (w.reshape(64, 64, 3) * 255).to(torch.uint8))
