@@ -147,12 +147,12 @@ __device__ __forceinline__ void stage_sync() {
 }
 
 #ifndef RN_XYZ_GROUP
-#define RN_XYZ_GROUP 2
+#define RN_XYZ_GROUP 1
 #endif
 #ifndef RN_AMB_GROUP
 #define RN_AMB_GROUP 4
 #endif
-constexpr int kXyzGroup = RN_XYZ_GROUP;  // xyz levels fetched together (each: 16 row words + 4 in flight)
+constexpr int kXyzGroup = RN_XYZ_GROUP;  // xyz levels fetched together; measured 1 / 2 / 4: one is best (hash19 -6 %), the partner wave covers
 constexpr int kAmbGroup = RN_AMB_GROUP;  // ambient-grid levels fetched together (each: 8 row words + 3)
 
 template <typename TX, typename TW>

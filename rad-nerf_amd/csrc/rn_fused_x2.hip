@@ -192,7 +192,7 @@ __device__ __forceinline__ void stage_sync() {
 }
 
 #ifndef RN_X2_XYZ_GROUP
-#define RN_X2_XYZ_GROUP 2
+#define RN_X2_XYZ_GROUP 1
 #endif
 constexpr int kXyzGroup = RN_X2_XYZ_GROUP;  // xyz levels fetched together (each: 16 row words + 4 in flight)
 
