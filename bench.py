@@ -192,8 +192,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RN_DIST_BACKEND", "nccl")      # "gloo": rehearse N ranks on ONE GPU (RCCL needs a GPU per rank)
+        if backend == "gloo":
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
@@ -240,7 +246,7 @@ def main():
                 short = 1
             barrier()
             elapsed = time.perf_counter() - t0
-            flag = torch.tensor([short], dtype=torch.int32, device=device)
+            flag = torch.tensor([short], dtype=torch.int32, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
             if dist is not None:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()) == 0:
@@ -264,7 +270,7 @@ def main():
             # untimed replay of a few of the timed frames to count live samples per frame
             live_pf, slots_pf = fpr.count_samples(list(range(W, W + min(K, 8))))
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

@@ -128,12 +128,15 @@ class FrameParallelRenderer(_Bookkeeping):
             if self.frames_u8 is None:
                 self.frames_u8 = torch.empty((self.world,) + tuple(u8.shape), dtype=torch.uint8, device=u8.device)
             # async: RCCL runs the gather on its own stream, overlapping the next frame's kernels
-            buf = torch.empty_like(self.frames_u8)
             if self.dist.get_backend() == "nccl":
+                buf = torch.empty_like(self.frames_u8)
                 work = self.dist.all_gather_into_tensor(buf, u8.contiguous(), async_op=True)
-            else:  # gloo (CPU tests)
-                work = self.dist.all_gather(list(buf.unbind(0)), u8.contiguous(), async_op=True)
-            self.pending.append((work, buf, u8))
+                self.pending.append((work, buf, u8))
+            else:  # gloo gathers host tensors (CPU tests, multi-rank rehearsals on a one-GPU box)
+                send = u8.contiguous().cpu()
+                buf = torch.empty((self.world,) + tuple(send.shape), dtype=torch.uint8)
+                work = self.dist.all_gather(list(buf.unbind(0)), send, async_op=True)
+                self.pending.append((work, buf, send))
         self.last_frame = u8
         self._frames_since_finish += 1
         return u8
