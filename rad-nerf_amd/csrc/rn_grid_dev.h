@@ -47,6 +47,22 @@ __device__ __forceinline__ void load_row(const T *p, T (&v)[C]) {
         reinterpret_cast<uint4 *>(v)[1] = reinterpret_cast<const uint4 *>(p)[1];
     }
 }
+// Streaming store of a feature row: the outputs are written once and never re-read by the kernel, so they should not
+// displace table lines from L2 (a hashed level of the T = 2^19 table is exactly one XCD's L2).
+template <typename T, uint32_t C>
+__device__ __forceinline__ void store_row_nt(T *p, const T (&v)[C]) {
+    constexpr uint32_t bytes = sizeof(T) * C;
+    if constexpr (bytes % 4 == 0) {
+        uint32_t w[bytes / 4];
+        __builtin_memcpy(w, v, bytes);
+#pragma unroll
+        for (uint32_t i = 0; i < bytes / 4; i++) __builtin_nontemporal_store(w[i], reinterpret_cast<uint32_t *>(p) + i);
+    } else {  // a single fp16 channel
+        uint16_t h;
+        __builtin_memcpy(&h, v, 2);
+        __builtin_nontemporal_store(h, reinterpret_cast<uint16_t *>(p));
+    }
+}
 template <typename T, uint32_t C>
 __device__ __forceinline__ void store_row(T *p, const T (&v)[C]) {
     constexpr uint32_t bytes = sizeof(T) * C;
