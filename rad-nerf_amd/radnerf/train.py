@@ -76,7 +76,13 @@ class Trainer:
     """zero_grad -> train_step -> backward -> Adam, with the occupancy grid refreshed every
     `update_extra_interval` steps as the reference's loop does under --cuda_ray (nerf/utils.py:1015-1018)."""
 
-    def __init__(self, model, opt, lr=5e-3, lr_net=5e-4, update_extra_interval=16, iters=200000, lambda_amb=0.1):
+    def __init__(self, model, opt, lr=5e-3, lr_net=5e-4, update_extra_interval=16, iters=200000, lambda_amb=0.1,
+                 prefer_rocblas=True):
+        # The weight gradients of the 64-wide MLPs are [64 x ~40 000] x [~40 000 x 96] products: all reduction, almost
+        # no output.  On this stack hipBLASLt runs them without a K split (132 us each, measured), rocBLAS in 37 us;
+        # eight of them per step make that the largest single item of the step.
+        if prefer_rocblas and torch.cuda.is_available() and getattr(torch.version, "hip", None):
+            torch.backends.cuda.preferred_blas_library("cublas")      # "cublas" selects rocBLAS on ROCm builds
         self.model, self.opt = model, opt
         self.optimizer = make_optimizer(model, lr, lr_net)
         self.update_extra_interval, self.iters, self.lambda_amb = update_extra_interval, iters, lambda_amb
