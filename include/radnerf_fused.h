@@ -106,25 +106,7 @@ typedef struct {
     float *sigmas, *rgbs;                 /* [N] [N,3] */
     int32_t *state;                       /* [RN_HEAD_STATE_INTS] */
     uint32_t *block_counts;               /* [2 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums */
-    /* optional accelerator (may be NULL): rn_coarse_occupancy(bitfield) -- one bit per 8x8x8 block of cells.  The march
-     * consults it before the bitfield: a clear bit proves the cell empty, so the dependent global load (and the morton
-     * code) of that lattice point is skipped.  Samples are bit-identical with and without it. */
-    const uint32_t *coarse;               /* [cascade * (grid_size / 8)^3 / 32] */
-    /* optional (both or neither): occ_box = world-space box around every set block (rn_coarse_occupancy), fars_walk =
-     * [N] scratch.  rn_head_begin then also intersects each ray with that box and the march stops where the ray leaves it
-     * (or does not start when it misses it): no occupied cell lies beyond, so the samples are unchanged; `fars` keeps the
-     * aabb exit for the depth normalisation (renderer.py:311). */
-    const float *occ_box;                 /* [6] xmin ymin zmin xmax ymax zmax */
-    float *fars_walk;                     /* [N] */
 } rn_head_t;
-
-/* coarse[c][(x * G + y) * G + z] (bit), G = H / 8 = any bit of the 8x8x8 block (x, y, z) of cascade c set in the morton
- * bitfield (raymarching.cu:214-243 layout).  Needs H % 8 == 0 and (H / 8)^3 % 32 == 0; recompute when the bitfield
- * changes (packbits, renderer.py:452).  occ_box (may be NULL): [6] floats, the world-space bounding box of all set blocks
- * over all cascades (cell i of cascade c spans ((i / H) * 2 - 1) * min(2^c, bound) ...), grown by one block on every
- * side; an empty grid gives an inverted box (min > max) that no ray hits. */
-int rn_coarse_occupancy(const uint8_t *bitfield, uint32_t cascade, uint32_t H, float bound, uint32_t *coarse,
-                        float *occ_box, rn_stream_t stream);
 
 /* near/far + loop initialisation (rays_alive = arange(N), rays_t = nears, accumulators = 0, step = 0). */
 int rn_head_begin(const rn_head_t *h, rn_stream_t stream);

@@ -29,7 +29,6 @@ struct Dda {
     float rH, H3, bound, dt_gamma, dt_min, dt_max, far, Cf, Hf;
     uint32_t H;
     const uint8_t *grid;
-    const uint32_t *coarse = nullptr;  // optional: one bit per 8^3 block, [level][(x*G + y)*G + z], G = H / 8 (may live in LDS)
 
     __device__ __forceinline__ void init(const float *o, const float *d, float bound_, float dt_gamma_,
                                          uint32_t max_steps, uint32_t C, uint32_t H_, const uint8_t *grid_,
@@ -45,19 +44,19 @@ struct Dda {
         dt_min = fminf(dt_max, 2 * kSqrt3 / (float)max_steps);   // :387
     }
 
-    // occupancy-grid cell of the lattice point at parameter t (raymarching.cu:404-417).
+    // occupancy-grid cell of the lattice point at parameter t (raymarching.cu:404-419); returns the bit index.
     //
     // :415-417 spell the cell coordinate as 0.5 * (double)(x * mip_rbound + 1) * (double)H, narrowed to float by
     // clamp().  v = x * mip_rbound + 1 has 24 significant bits and H < 2^24, so the double product v * H / 2 is exact
     // and its narrowing is the correctly rounded value of v * H / 2 -- which is what the single fp32 multiply
     // v * (0.5f * H) returns (0.5 * H is exact).  Same bits, no fp64.  With one cascade the level is 0 for every point.
-    __device__ __forceinline__ void cell_coords(float t, float &x, float &y, float &z, float &dt, float &mip_bound, int &nx,
-                                                int &ny, int &nz, int &level) const {
+    __device__ __forceinline__ uint32_t cell_of(float t, float &x, float &y, float &z, float &dt, float &mip_bound, int &nx,
+                                                int &ny, int &nz) const {
         x = clampf(ox + t * dx, -bound, bound);
         y = clampf(oy + t * dy, -bound, bound);
         z = clampf(oz + t * dz, -bound, bound);
         dt = clampf(t * dt_gamma, dt_min, dt_max);
-        level = 0;
+        int level = 0;
         if (Cf > 1.0f) {  // wave-uniform
             const int lp = mip_from_pos(x, y, z, Cf), ld = mip_from_dt(dt, Hf, Cf);
             level = lp > ld ? lp : ld;
@@ -68,6 +67,8 @@ struct Dda {
         nx = (int)clampf((x * mip_rbound + 1) * half_h, 0.0f, top);
         ny = (int)clampf((y * mip_rbound + 1) * half_h, 0.0f, top);
         nz = (int)clampf((z * mip_rbound + 1) * half_h, 0.0f, top);
+        // :419 -- evaluated in float (H3 is a float in the reference)
+        return (uint32_t)((float)level * H3 + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
     }
 
     // Walk from t, at most `limit` occupied steps.  EMIT writes samples to xyzs/dirs/deltas.
@@ -83,20 +84,8 @@ struct Dda {
         while (t < far && step < limit && guard < (1u << 20)) {
             float x, y, z, dt, mip_bound;
             int nx, ny, nz;
-            int level;
-            cell_coords(t, x, y, z, dt, mip_bound, nx, ny, nz, level);
-            bool occ = true;
-            if (coarse) {  // a clear block bit proves the cell empty without touching the bitfield
-                const uint32_t G = H >> 3;
-                const uint32_t c = (uint32_t)level * G * G * G + (((uint32_t)nx >> 3) * G + ((uint32_t)ny >> 3)) * G + ((uint32_t)nz >> 3);
-                occ = (coarse[c >> 5] >> (c & 31u)) & 1u;
-            }
-            if (occ) {
-                // :419 -- evaluated in float (H3 is a float in the reference)
-                const uint32_t index = (uint32_t)((float)level * H3 + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-                occ = grid[index >> 3] & (1u << (index & 7u));
-            }
-            if (occ) {
+            const uint32_t index = cell_of(t, x, y, z, dt, mip_bound, nx, ny, nz);
+            if (grid[index >> 3] & (1u << (index & 7u))) {
                 if (EMIT) {
                     xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
                     dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;

@@ -320,7 +320,6 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
 //   [0] n_alive  [1] step  [2] n_step  [3] M = n_alive * n_step  [4] active
 // plus stats at [16..]: iterations that did work, live samples, sample slots.
 constexpr int kLoopBlock = 256;
-constexpr int kCoarseLdsWords = 512;  // 16^3 blocks x up to 4 cascades
 
 __device__ __forceinline__ void next_state(int32_t *st, uint32_t N, uint32_t n_alive, uint32_t step, uint32_t max_steps) {
     uint32_t n_step = n_alive ? N / n_alive : 1u;   // max(min(N // n_alive, 8), 1)  (renderer.py:249)
@@ -339,8 +338,7 @@ __global__ void __launch_bounds__(kLoopBlock)
 k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
              uint32_t N, float min_near, uint32_t max_steps, float *__restrict__ nears, float *__restrict__ fars,
              float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
-             int32_t *__restrict__ rays_alive, float *__restrict__ rays_t, int32_t *__restrict__ state,
-             const float *__restrict__ occ_box, float *__restrict__ fars_walk) {
+             int32_t *__restrict__ rays_alive, float *__restrict__ rays_t, int32_t *__restrict__ state) {
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     if (n == 0) {
         next_state(state, N, N, 0, max_steps);
@@ -370,22 +368,6 @@ k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     near = miss ? FLT_MAX : near;
     far = miss ? FLT_MAX : far;
     nears[n] = near; fars[n] = far;
-    if (fars_walk) {
-        // where the ray leaves the box around all occupied blocks (slab test); beyond it every lattice point is empty
-        float fw = far;
-        if (occ_box && !miss) {
-            float t0 = (occ_box[0] - ox) * rdx, t1 = (occ_box[3] - ox) * rdx;
-            float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
-            t0 = (occ_box[1] - oy) * rdy; t1 = (occ_box[4] - oy) * rdy;
-            lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
-            t0 = (occ_box[2] - oz) * rdz; t1 = (occ_box[5] - oz) * rdz;
-            lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
-            // NaNs (a ray parallel to a slab inside it: 0 * inf) fall through the comparisons to "keep far"
-            if (lo > hi || occ_box[0] > occ_box[3]) fw = near;       // misses the box: nothing to march
-            else if (hi < far) fw = fmaxf(hi, near);
-        }
-        fars_walk[n] = fw;
-    }
     rays_t[n] = near;
     rays_alive[n] = (int32_t)n;
     weights_sum[n] = 0.0f; depth[n] = 0.0f;
@@ -398,19 +380,9 @@ __global__ void __launch_bounds__(kLoopBlock)
 k_head_march(const int32_t *__restrict__ st, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
              const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, float dt_gamma,
              uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
-             const uint32_t *__restrict__ coarse, uint32_t coarse_words, const float *__restrict__ fars,
-             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ stats,
+             const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ stats,
              uint32_t *__restrict__ block_live) {
-    // Rays that have left the head walk on through empty cells until `far`; a wave lasts as long as its slowest ray, so
-    // the cost of an EMPTY lattice point sets the kernel's time.  The block-occupancy words (<= 2 KB) sit in LDS: an
-    // empty block is recognised without the dependent global load of the bitfield.
-    __shared__ uint32_t coarse_lds[kCoarseLdsWords];
     if (!st[4]) return;
-    const bool use_coarse = coarse != nullptr && coarse_words <= (uint32_t)kCoarseLdsWords;
-    if (use_coarse) {
-        for (uint32_t i = threadIdx.x; i < coarse_words; i += kLoopBlock) coarse_lds[i] = coarse[i];
-        __syncthreads();
-    }
     const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     uint32_t emitted = 0;
@@ -418,7 +390,6 @@ k_head_march(const int32_t *__restrict__ st, const int32_t *__restrict__ rays_al
         const int index = rays_alive[n];
         Dda s;
         s.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
-        if (use_coarse) s.coarse = coarse_lds;
         float t = rays_t[index];  // perturb is off at inference: no noise term (renderer.py:251)
         const size_t base = (size_t)n * n_step;
         emitted = s.walk<true>(t, n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
@@ -536,63 +507,6 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
         for (int w = 0; w < kLoopBlock / kWave; w++) sum += red_live[w];
         if (sum) atomicAdd(&stats[RN_HEAD_ST_LIVE], (int32_t)sum);
     }
-}
-
-// One bit per 8x8x8 block of occupancy cells.  In morton order the 512 cells of a block are 512 consecutive bits = 64
-// consecutive bytes of the bitfield (the block's morton code is the cell's >> 9), so a lane ORs 16 words.
-__global__ void __launch_bounds__(256) k_coarse_occupancy(const uint8_t *__restrict__ bitfield, uint32_t C, uint32_t G,
-                                                          uint32_t *__restrict__ coarse) {
-    const uint32_t blocks = G * G * G;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // (cascade, block in morton order)
-    const bool in_range = i < C * blocks;
-    uint32_t any = 0, c = 0;
-    if (in_range) {
-        const uint32_t level = i / blocks, m = i - level * blocks;
-        const uint4 *p = reinterpret_cast<const uint4 *>(bitfield + ((size_t)level * blocks + m) * 64);
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const uint4 v = p[q]; any |= v.x | v.y | v.z | v.w; }
-        const uint32_t x = morton3D_invert(m), y = morton3D_invert(m >> 1), z = morton3D_invert(m >> 2);
-        c = level * blocks + (x * G + y) * G + z;
-    }
-    if (in_range && any) atomicOr(&coarse[c >> 5], 1u << (c & 31u));
-}
-
-// World-space box around every set block, grown by one block per side (one workgroup; the block grid is tiny).
-__global__ void __launch_bounds__(256) k_occupancy_box(const uint32_t *__restrict__ coarse, uint32_t C, uint32_t G, float bound,
-                                                       float *__restrict__ box) {
-    __shared__ float red[4][6];
-    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    const uint32_t blocks = G * G * G;
-    for (uint32_t i = threadIdx.x; i < C * blocks; i += 256) {
-        if (!((coarse[i >> 5] >> (i & 31u)) & 1u)) continue;
-        const uint32_t level = i / blocks, r = i - level * blocks;
-        const uint32_t c[3] = {r / (G * G), (r / G) % G, r % G};
-        const float mip_bound = fminf(scalbnf(1.0f, (int)level), bound);
-#pragma unroll
-        for (int d = 0; d < 3; d++) {  // cells 8 c - 8 .. 8 c + 15: the block and one block on either side
-            lo[d] = fminf(lo[d], (((float)c[d] - 1.0f) / (float)G * 2 - 1) * mip_bound);
-            hi[d] = fmaxf(hi[d], (((float)c[d] + 2.0f) / (float)G * 2 - 1) * mip_bound);
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; d++)
-        for (int off = 32; off > 0; off >>= 1) {
-            lo[d] = fminf(lo[d], __shfl_down(lo[d], off, 64));
-            hi[d] = fmaxf(hi[d], __shfl_down(hi[d], off, 64));
-        }
-    if ((threadIdx.x & 63) == 0)
-        for (int d = 0; d < 3; d++) { red[threadIdx.x >> 6][d] = lo[d]; red[threadIdx.x >> 6][3 + d] = hi[d]; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int d = threadIdx.x;
-        box[d] = fminf(fminf(red[0][d], red[1][d]), fminf(red[2][d], red[3][d]));
-        box[3 + d] = fmaxf(fmaxf(red[0][3 + d], red[1][3 + d]), fmaxf(red[2][3 + d], red[3][3 + d]));
-    }
-}
-
-static inline uint32_t coarse_words(uint32_t cascade, uint32_t H) {
-    const uint32_t G = H / 8;
-    return (cascade * G * G * G + 31u) / 32u;
 }
 
 // Was the loop over after the iterations the caller enqueued?  (`st` = the state bank the NEXT iteration would read.)
@@ -1016,7 +930,7 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream) {
     if (int rc = check_head(h)) return rc;
     hipLaunchKernelGGL(k_head_begin, dim3(div_up(h->N, kLoopBlock)), dim3(kLoopBlock), 0, as_stream(stream), h->rays_o,
                        h->rays_d, h->aabb, h->N, h->min_near, h->max_steps, h->nears, h->fars, h->weights_sum, h->depth,
-                       h->image, h->rays_alive_a, h->rays_t, h->state, h->fars_walk ? h->occ_box : nullptr, h->fars_walk);
+                       h->image, h->rays_alive_a, h->rays_t, h->state);
     return check_launch("head_begin");
 }
 
@@ -1036,8 +950,7 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
         int32_t *alive = (it & 1u) ? h->rays_alive_b : h->rays_alive_a;
         int32_t *alive_next = (it & 1u) ? h->rays_alive_a : h->rays_alive_b;
         hipLaunchKernelGGL(k_head_march, rgrid, rblock, 0, s, st, alive, h->rays_t, h->rays_o, h->rays_d, h->bound,
-                           h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->coarse,
-                           coarse_words(h->cascade, h->grid_size), h->fars_walk ? h->fars_walk : h->fars, h->xyzs, h->dirs,
+                           h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
                            h->deltas, h->state, block_live);
         run_fused(h->xyzs, h->dirs, h->deltas, h->N, st + 3, grid_xyz, grid_amb, packed, bias, h->bound, h->sigmas, h->rgbs,
                   nullptr, mlp_dtype, s);
@@ -1047,18 +960,6 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
                            h->block_counts, block_live, h->state);
     }
     return check_launch("head_iterate");
-}
-
-int rn_coarse_occupancy(const uint8_t *bitfield, uint32_t cascade, uint32_t H, float bound, uint32_t *coarse, float *occ_box,
-                        rn_stream_t stream) {
-    RN_REQUIRE(bitfield && coarse, "coarse_occupancy: null pointer");
-    RN_REQUIRE(cascade >= 1 && H >= 8 && H % 8 == 0 && ((uintptr_t)bitfield & 15u) == 0,
-               "coarse_occupancy: grid size must be a multiple of 8 and the bitfield 16-byte aligned");
-    const uint32_t G = H / 8, n = cascade * G * G * G;
-    (void)hipMemsetAsync(coarse, 0, (size_t)coarse_words(cascade, H) * 4, as_stream(stream));
-    hipLaunchKernelGGL(k_coarse_occupancy, dim3(div_up(n, 256)), dim3(256), 0, as_stream(stream), bitfield, cascade, G, coarse);
-    if (occ_box) hipLaunchKernelGGL(k_occupancy_box, dim3(1), dim3(256), 0, as_stream(stream), coarse, cascade, G, bound, occ_box);
-    return check_launch("coarse_occupancy");
 }
 
 int rn_head_check_done(const rn_head_t *h, uint32_t iters_done, rn_stream_t stream) {

@@ -46,7 +46,7 @@ class HeadT(C.Structure):
                 ("grid_size", _u32), ("T_thresh", _f32), ("nears", _ptr), ("fars", _ptr), ("weights_sum", _ptr),
                 ("depth", _ptr), ("image", _ptr), ("rays_alive_a", _ptr), ("rays_alive_b", _ptr), ("rays_t", _ptr),
                 ("xyzs", _ptr), ("dirs", _ptr), ("deltas", _ptr), ("sigmas", _ptr), ("rgbs", _ptr), ("state", _ptr),
-                ("block_counts", _ptr), ("coarse", _ptr), ("occ_box", _ptr), ("fars_walk", _ptr)]
+                ("block_counts", _ptr)]
 
 
 RN_HEAD_STATE_INTS = 32
@@ -64,7 +64,6 @@ _SIGS = {
     "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, C.c_int, _ptr],
     "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
     "rn_head_check_done": [C.POINTER(HeadT), _u32, _ptr],
-    "rn_coarse_occupancy": [_ptr, _u32, _u32, _f32, _ptr, _ptr, _ptr],
     "rn_get_rays": [_ptr, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
     "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
@@ -137,25 +136,6 @@ class FusedState:
         self._N = 0
         self._zero_eye = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
-    # -- occupancy accelerator ------------------------------------------------------------------------
-    def coarse_occupancy(self):
-        """Device pointer of the block-occupancy bits of model.density_bitfield (rebuilt when the bitfield changes), or
-        None when the grid size is not a multiple of 8."""
-        m = self.model
-        bf = m.density_bitfield
-        H, Cn = int(m.grid_size), int(m.cascade)
-        if H % 8 or (bf.data_ptr() & 15) or getattr(m.opt, "coarse_occupancy", True) is False:
-            return None
-        key = (bf._version, bf.data_ptr())
-        if getattr(self, "_coarse_key", None) != key:
-            words = (Cn * (H // 8) ** 3 + 31) // 32
-            self._coarse = torch.empty(words, dtype=torch.int32, device=bf.device)
-            self._occ_box = torch.empty(6, dtype=torch.float32, device=bf.device)
-            hip.call("rn_coarse_occupancy", hip.ptr(bf), Cn, H, float(m.bound), hip.ptr(self._coarse), hip.ptr(self._occ_box),
-                     hip.stream())
-            self._coarse_key = key
-        return self._coarse.data_ptr()
-
     # -- weights --------------------------------------------------------------------------------------
     def _weights(self):
         m = self.model
@@ -211,7 +191,6 @@ class FusedState:
         d, f32, i32 = self.dev, torch.float32, torch.int32
         self.nears = torch.empty(N, dtype=f32, device=d)
         self.fars = torch.empty(N, dtype=f32, device=d)
-        self.fars_walk = torch.empty(N, dtype=f32, device=d)
         self.rays_alive = torch.empty(2, N, dtype=i32, device=d)
         self.rays_t = torch.empty(N, dtype=f32, device=d)
         self.samples = torch.empty(N * 8, dtype=f32, device=d)   # xyzs | dirs | deltas
@@ -339,9 +318,6 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     h.deltas = st.samples.data_ptr() + N * 6 * 4
     h.sigmas, h.rgbs = st.sigmas.data_ptr(), st.rgbs.data_ptr()
     h.state, h.block_counts = st.state.data_ptr(), st.block_counts.data_ptr()
-    h.coarse = st.coarse_occupancy()
-    if h.coarse:
-        h.occ_box, h.fars_walk = st._occ_box.data_ptr(), st.fars_walk.data_ptr()
 
     # The whole <= max_steps loop is enqueued without reading anything back: iterations past the end of the loop
     # are no-ops decided on the device (a few microseconds each), so the host can run ahead of the GPU.

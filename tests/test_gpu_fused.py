@@ -343,36 +343,3 @@ def test_frame_parallel_renderer_learns_the_loop_length(hiplib):
         fpr.finish()                                   # would raise LoopHintTooSmall
     for g, w in zip(got, want):
         assert torch.equal(g, (w.reshape(64, 64, 3) * 255).to(torch.uint8))
-
-
-def test_coarse_occupancy_bits_and_identical_frames(po, hiplib):
-    """rn_coarse_occupancy: bit (x, y, z) of cascade c = any cell of that 8^3 block set in the morton bitfield; frames
-    rendered with and without the accelerator are identical (a clear block bit only proves cells empty)."""
-    import radnerf_hip as hip
-    from radnerf import fused
-    from radnerf.scene import morton3d_np
-    scene = _scene(64, "fused")
-    m = scene.model
-    H = m.grid_size
-    bits = np.unpackbits(m.density_bitfield.cpu().numpy(), bitorder="little")[:H ** 3]
-    idx = np.arange(H)
-    X, Y, Z = np.meshgrid(idx, idx, idx, indexing="ij")
-    dense = np.zeros((H, H, H), bool)
-    dense[X, Y, Z] = bits[morton3d_np(X.reshape(-1), Y.reshape(-1), Z.reshape(-1)).astype(np.int64)].reshape(H, H, H)
-    G = H // 8
-    want = dense.reshape(G, 8, G, 8, G, 8).any(axis=(1, 3, 5)).reshape(-1)
-    st = fused._state(m)
-    assert st.coarse_occupancy() is not None
-    got = np.unpackbits(st._coarse.cpu().numpy().view(np.uint8), bitorder="little")[:G ** 3].astype(bool)
-    assert np.array_equal(got, want) and 0 < want.sum() < want.size
-    # world box around the set blocks, grown by one block: cell i spans ((i / H) * 2 - 1) * bound ...
-    bx = np.where(want.reshape(G, G, G))
-    box = st._occ_box.cpu().numpy()
-    for d in range(3):
-        assert abs(box[d] - ((bx[d].min() - 1) / G * 2 - 1)) < 1e-6 and abs(box[3 + d] - ((bx[d].max() + 2) / G * 2 - 1)) < 1e-6
-    with torch.no_grad():
-        a = scene.render(0)["image"].clone()
-        m.opt.coarse_occupancy = False
-        m.enc_a = None
-        b = scene.render(0)["image"]
-    assert torch.equal(a, b)
