@@ -105,7 +105,7 @@ typedef struct {
     float *xyzs, *dirs, *deltas;          /* [N,3] [N,3] [N,2] */
     float *sigmas, *rgbs;                 /* [N] [N,3] */
     int32_t *state;                       /* [RN_HEAD_STATE_INTS] */
-    uint32_t *block_counts;               /* [2 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums */
+    uint32_t *block_counts;               /* [3 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums x 2 */
 } rn_head_t;
 
 /* near/far + loop initialisation (rays_alive = arange(N), rays_t = nears, accumulators = 0, step = 0). */

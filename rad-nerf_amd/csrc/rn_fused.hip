@@ -317,20 +317,25 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
 // Device-side inference loop (nerf/renderer.py:225-262)
 //
 // state words (int32), two banks of 8 selected by (iteration & 1):
-//   [0] n_alive  [1] step  [2] n_step  [3] M = n_alive * n_step  [4] active
+//   [0] n_alive  [1] step  [2] n_step  [3] M = n_alive * n_step  [4] active  [5] live-partial workgroups (0: default)
 // plus stats at [16..]: iterations that did work, live samples, sample slots.
 constexpr int kLoopBlock = 256;
 
-__device__ __forceinline__ void next_state(int32_t *st, uint32_t N, uint32_t n_alive, uint32_t step, uint32_t max_steps) {
+__device__ __forceinline__ uint32_t policy_n_step(uint32_t N, uint32_t n_alive) {
     uint32_t n_step = n_alive ? N / n_alive : 1u;   // max(min(N // n_alive, 8), 1)  (renderer.py:249)
     n_step = n_step > 8u ? 8u : n_step;
-    n_step = n_step < 1u ? 1u : n_step;
+    return n_step < 1u ? 1u : n_step;
+}
+
+__device__ __forceinline__ void next_state(int32_t *st, uint32_t N, uint32_t n_alive, uint32_t step, uint32_t max_steps) {
+    const uint32_t n_step = policy_n_step(N, n_alive);
     const bool active = step < max_steps && n_alive > 0;
     st[0] = (int32_t)n_alive;
     st[1] = (int32_t)step;
     st[2] = (int32_t)n_step;
     st[3] = active ? (int32_t)(n_alive * n_step) : 0;  // sample slots of the coming iteration (0: loop is over)
     st[4] = active ? 1 : 0;
+    st[5] = 0;  // workgroups that hold live-sample partial sums of the coming iteration; 0 = ceil(n_alive / 256)
 }
 
 // near/far (raymarching.cu:91-145) + loop initialisation (renderer.py:229-237)
@@ -461,13 +466,29 @@ k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__rest
     }
 }
 
-// stable compaction (renderer.py:258) + loop control (renderer.py:242-249, 262) for the next iteration
+// stable compaction (renderer.py:258) + loop control (renderer.py:242-249, 262) for the next iteration and, with MARCH,
+// the next iteration's march as well: every workgroup adds up all survivor counts (<= 1024 words), so it knows the new
+// n_alive and n_step, and a surviving ray is marched by the lane that has just computed its slot in the new list.  One
+// launch (and one pass over the ray list) less per iteration; the lanes of dead rays idle, which costs nothing here:
+// these launches are bound by the length of one ray's walk, not by lane throughput.
+struct MarchArgs {
+    const float *rays_t, *rays_o, *rays_d, *fars;
+    float bound, dt_gamma;
+    uint32_t cascade, grid_size;
+    const uint8_t *grid;
+    float *xyzs, *dirs, *deltas;
+    uint32_t *block_live_next;
+};
+
+template <bool MARCH>
 __global__ void __launch_bounds__(kLoopBlock)
 k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps,
                const int32_t *__restrict__ rays_in, int32_t *__restrict__ rays_out,
-               const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats) {
+               const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats,
+               MarchArgs m) {
     __shared__ uint32_t red[kLoopBlock / kWave];
     __shared__ uint32_t red_live[kLoopBlock / kWave];
+    __shared__ uint32_t red_all[kLoopBlock / kWave];
     __shared__ uint32_t wave_off[kLoopBlock / kWave];
     if (!st[4]) {
         if (blockIdx.x == 0 && threadIdx.x < 8) st_next[threadIdx.x] = st[threadIdx.x];
@@ -476,16 +497,25 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
     const uint32_t n_alive = (uint32_t)st[0];
     const uint32_t n_blocks = (n_alive + kLoopBlock - 1) / kLoopBlock;
     if (blockIdx.x >= n_blocks) return;
+    const bool last = blockIdx.x == n_blocks - 1;
 
-    uint32_t part = 0, live = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kLoopBlock) part += block_counts[b];
-    if (blockIdx.x == n_blocks - 1)  // the last workgroup also adds up the march kernel's live-sample partial sums
-        for (uint32_t b = threadIdx.x; b < n_blocks; b += kLoopBlock) live += block_live[b];
-    for (int off = 32; off > 0; off >>= 1) { part += __shfl_down(part, off, 64); live += __shfl_down(live, off, 64); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = part; red_live[threadIdx.x >> 6] = live; }
+    uint32_t part = 0, live = 0, all = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kLoopBlock) {
+        const uint32_t c = block_counts[b];
+        all += c;
+        part += b < blockIdx.x ? c : 0u;
+    }
+    if (last) {  // the last workgroup also adds up the live-sample partial sums of this iteration's march
+        const uint32_t n_live = st[5] ? (uint32_t)st[5] : n_blocks;
+        for (uint32_t b = threadIdx.x; b < n_live; b += kLoopBlock) live += block_live[b];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        part += __shfl_down(part, off, 64); live += __shfl_down(live, off, 64); all += __shfl_down(all, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = part; red_live[threadIdx.x >> 6] = live; red_all[threadIdx.x >> 6] = all; }
     __syncthreads();
-    uint32_t offset = 0;
-    for (int w = 0; w < kLoopBlock / kWave; w++) offset += red[w];
+    uint32_t offset = 0, n_next = 0;
+    for (int w = 0; w < kLoopBlock / kWave; w++) { offset += red[w]; n_next += red_all[w]; }
 
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     const int32_t v = (n < n_alive) ? rays_in[n] : -1;
@@ -494,18 +524,46 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
     const uint32_t within = ballot_prefix(mask);
     if ((threadIdx.x & 63) == 0) wave_off[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
     __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < kLoopBlock / kWave; w++) {
-        const uint32_t cw = wave_off[w];
-        before += (w < (threadIdx.x >> 6)) ? cw : 0u;
-        total += cw;
-    }
-    if (keep) rays_out[offset + before + within] = v;
-    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) {
-        next_state(st_next, N, offset + total, (uint32_t)st[1] + (uint32_t)st[2], max_steps);
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wave_off[w];
+    const uint32_t slot = offset + before + within;
+    if (keep) rays_out[slot] = v;
+
+    const uint32_t step_next = (uint32_t)st[1] + (uint32_t)st[2];
+    const uint32_t n_step_next = policy_n_step(N, n_next);
+    const bool active_next = step_next < max_steps && n_next > 0;
+    if (last && threadIdx.x == 0) {
+        next_state(st_next, N, n_next, step_next, max_steps);
         uint32_t sum = 0;
         for (int w = 0; w < kLoopBlock / kWave; w++) sum += red_live[w];
         if (sum) atomicAdd(&stats[RN_HEAD_ST_LIVE], (int32_t)sum);
+        if (MARCH && active_next) {
+            st_next[5] = (int32_t)n_blocks;  // the partial sums written below are indexed by THIS launch's workgroups
+            atomicAdd(&stats[RN_HEAD_ST_ITERS], 1);
+            atomicAdd(&stats[RN_HEAD_ST_SLOTS], (int32_t)(n_next * n_step_next));
+        }
+    }
+    if constexpr (MARCH) {
+        if (!active_next) return;  // uniform
+        uint32_t emitted = 0;
+        if (keep) {
+            Dda s;
+            s.init(m.rays_o + (size_t)v * 3, m.rays_d + (size_t)v * 3, m.bound, m.dt_gamma, max_steps, m.cascade, m.grid_size, m.grid,
+                   m.fars[v]);
+            float t = m.rays_t[v];
+            const size_t base = (size_t)slot * n_step_next;
+            emitted = s.walk<true>(t, n_step_next, m.xyzs + base * 3, m.dirs + base * 3, m.deltas + base * 2);
+            for (uint32_t k = emitted; k < n_step_next; k++) { m.deltas[(base + k) * 2] = 0.0f; m.deltas[(base + k) * 2 + 1] = 0.0f; }
+        }
+        __syncthreads();  // red / wave_off are reused below
+        for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = emitted;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < kLoopBlock / kWave; w++) sum += red[w];
+            m.block_live_next[blockIdx.x] = sum;
+        }
     }
 }
 
@@ -944,20 +1002,32 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
     if (int rc = check_grid(grid_amb, 2, "head_iterate(ambient grid)")) return rc;
     hipStream_t s = as_stream(stream);
     const dim3 rgrid(div_up(h->N, kLoopBlock)), rblock(kLoopBlock);
-    uint32_t *block_live = h->block_counts + div_up(h->N, kLoopBlock) + 1;  // second half of the caller's scratch
+    // caller's scratch: survivor counts | live-sample partial sums of even iterations | ... of odd iterations
+    const uint32_t nb = div_up(h->N, kLoopBlock) + 1;
+    uint32_t *block_live[2] = {h->block_counts + nb, h->block_counts + 2 * nb};
     for (uint32_t it = first_iter; it < first_iter + n_iters; it++) {
         int32_t *st = h->state + (it & 1u) * 8, *st_next = h->state + ((it + 1) & 1u) * 8;
         int32_t *alive = (it & 1u) ? h->rays_alive_b : h->rays_alive_a;
         int32_t *alive_next = (it & 1u) ? h->rays_alive_a : h->rays_alive_b;
-        hipLaunchKernelGGL(k_head_march, rgrid, rblock, 0, s, st, alive, h->rays_t, h->rays_o, h->rays_d, h->bound,
-                           h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
-                           h->deltas, h->state, block_live);
+        // A call marches its own first iteration; after that the compaction kernel marches the next iteration itself.
+        // The last compaction of a call does not, so that a caller may adjust the schedule between calls
+        // (rn_head_reschedule) -- enqueueing the loop one iteration per call reproduces the four-kernel sequence.
+        if (it == first_iter)
+            hipLaunchKernelGGL(k_head_march, rgrid, rblock, 0, s, st, alive, h->rays_t, h->rays_o, h->rays_d, h->bound,
+                               h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
+                               h->deltas, h->state, block_live[it & 1u]);
         run_fused(h->xyzs, h->dirs, h->deltas, h->N, st + 3, grid_xyz, grid_amb, packed, bias, h->bound, h->sigmas, h->rgbs,
                   nullptr, mlp_dtype, s);
         hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
                            h->deltas, h->weights_sum, h->depth, h->image, h->block_counts);
-        hipLaunchKernelGGL(k_head_compact, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
-                           h->block_counts, block_live, h->state);
+        const MarchArgs m{h->rays_t, h->rays_o, h->rays_d, h->fars, h->bound, h->dt_gamma, h->cascade, h->grid_size, h->bitfield,
+                          h->xyzs, h->dirs, h->deltas, block_live[(it + 1) & 1u]};
+        if (it + 1 < first_iter + n_iters)
+            hipLaunchKernelGGL(k_head_compact<true>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
+                               h->block_counts, block_live[it & 1u], h->state, m);
+        else
+            hipLaunchKernelGGL(k_head_compact<false>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
+                               h->block_counts, block_live[it & 1u], h->state, m);
     }
     return check_launch("head_iterate");
 }

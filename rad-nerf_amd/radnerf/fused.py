@@ -198,7 +198,7 @@ class FusedState:
         self.rgbs = torch.empty(N, 3, dtype=f32, device=d)
         self.state = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32, device=d)
         self.stats_prev = [0, 0, 0]
-        self.block_counts = torch.empty(2 * ((N + 255) // 256 + 1), dtype=i32, device=d)
+        self.block_counts = torch.empty(3 * ((N + 255) // 256 + 1), dtype=i32, device=d)
         self._N = N
 
 
