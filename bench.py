@@ -215,7 +215,7 @@ def main():
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
                            opt=default_opt(engine=engine, mlp_dtype=args.mlp, **GRIDS[args.grid]))
     tile = args.workload == "tile"
-    fpr = (TileParallelRenderer(scene, rank, world, dist) if tile else
+    fpr = (TileParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint) if tile else
            FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint))
 
     def barrier():

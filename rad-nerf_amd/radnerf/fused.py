@@ -334,13 +334,16 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
         # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.
         group, n_total = shard
         total = torch.empty(1, dtype=torch.int32, device=dev)
-        for it in range(int(max_steps)):
+        n_iters = int(max_steps) if st.loop_hint is None else min(int(max_steps), st.loop_hint)
+        for it in range(n_iters):
             hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias),
                      it, 1, st.mlp_dtype, s)
             bank = ((it + 1) & 1) * 8
             total.copy_(st.state[bank:bank + 1])
             group.all_reduce(total)
             hip.call("rn_head_reschedule", C.byref(h), it, int(n_total), hip.ptr(total), hip.stream())
+        if n_iters < int(max_steps):
+            hip.call("rn_head_check_done", C.byref(h), n_iters, s)
 
     # torso layer over the background
     bg_in = None

@@ -41,7 +41,24 @@ def skipped_frames(step, rank, world):
 
 
 class _Bookkeeping:
-    """What bench.py reads from either renderer."""
+    """What bench.py reads from either renderer, and the speculative loop length both can use."""
+
+    def _update_loop_hint(self):
+        from . import fused
+        m = self.scene.model
+        cur = fused.loop_counters(m)                # synchronises; finish() is a synchronisation point anyway
+        unfinished = fused.unfinished_frames(m)
+        prev, self._counters = self._counters, (cur, unfinished)
+        if cur is None or not self._frames_since_finish:
+            return
+        if prev is not None and unfinished != prev[1]:
+            fused.set_loop_hint(m, None)
+            self._frames_since_finish = 0
+            raise LoopHintTooSmall(f"{unfinished - prev[1]} frame(s) needed more loop iterations than the hint")
+        iters = ((cur[0] - (prev[0][0] if prev else 0)) & 0xFFFFFFFF) / self._frames_since_finish
+        fused.set_loop_hint(m, int(-(-iters // 1)) + 2)
+        self._frames_since_finish = 0
+
 
     # -- bookkeeping for bench.py -------------------------------------------------------------------
     def loop_counters(self):
@@ -141,22 +158,6 @@ class FrameParallelRenderer(_Bookkeeping):
         self._frames_since_finish += 1
         return u8
 
-    def _update_loop_hint(self):
-        from . import fused
-        m = self.scene.model
-        cur = fused.loop_counters(m)                # synchronises; finish() is a synchronisation point anyway
-        unfinished = fused.unfinished_frames(m)
-        prev, self._counters = self._counters, (cur, unfinished)
-        if cur is None or not self._frames_since_finish:
-            return
-        if prev is not None and unfinished != prev[1]:
-            fused.set_loop_hint(m, None)
-            self._frames_since_finish = 0
-            raise LoopHintTooSmall(f"{unfinished - prev[1]} frame(s) needed more loop iterations than the hint")
-        iters = ((cur[0] - (prev[0][0] if prev else 0)) & 0xFFFFFFFF) / self._frames_since_finish
-        fused.set_loop_hint(m, int(-(-iters // 1)) + 2)
-        self._frames_since_finish = 0
-
     def _render_for_count(self, step):
         self.scene.render(frame_of(step, self.rank, self.world))
 
@@ -184,7 +185,7 @@ class TileParallelRenderer(_Bookkeeping):
     """BASELINE config 4 (a single 1024^2 frame over 8 GPUs).  `step(i)` renders this rank's rows of global frame i
     and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (identical on every rank)."""
 
-    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule=None):
+    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule=None, speculate_loop=False):
         """schedule="frame": the ranks agree on the whole frame's step schedule (one 4-byte all-reduce per loop
         iteration, enqueued on the device; fused engine only) so the assembled image IS the whole-frame render;
         schedule="band": no collective inside the loop, each band follows the reference's policy for its own rays.
@@ -198,6 +199,9 @@ class TileParallelRenderer(_Bookkeeping):
                 raise RuntimeError("schedule='frame' needs the fused engine (device-resident loop state)")
             scene.model.shard_schedule = (dist, scene.H * scene.W)
         self.schedule = schedule
+        self.speculate_loop = speculate_loop and fused_engine      # as in FrameParallelRenderer
+        self._frames_since_finish = 0
+        self._counters = None
         H, W = scene.H, scene.W
         self.rows = [stripe_rows(H, r, world, band) for r in range(world)]
         self.n_max = max(len(r) for r in self.rows)
@@ -230,6 +234,7 @@ class TileParallelRenderer(_Bookkeeping):
 
     def step(self, i):
         u8 = self.render_local(i)
+        self._frames_since_finish += 1
         if self.dist is None or self.world == 1:
             self.pending.append((None, None, u8))
             return u8
@@ -264,4 +269,6 @@ class TileParallelRenderer(_Bookkeeping):
                 work.wait()
                 frames.append(self.assemble(buf))
         self.pending = []
+        if self.speculate_loop:
+            self._update_loop_hint()
         return frames
