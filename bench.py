@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--rays", type=int, default=4096, help="rays per training step (--workload train)")
     ap.add_argument("--mlp", default="f32", choices=["f32", "f32x2", "f16"],
                     help="arithmetic of the fused kernel's contractions: f32 = v_mfma_f32_32x32x2_f32 (headline, fp32 parity); "
-                         "f16 = v_mfma_f32_32x32x16_f16 with fp32 accumulation (the reference's -O/autocast arithmetic)")
+                         "f32x2 = fp16 hi+lo operand pairs on the f16 matrix cores (fp32-grade); f16 = fp16 operands, fp32 "
+                         "accumulation (the reference's -O/autocast arithmetic)")
     ap.add_argument("--no-loop-hint", action="store_true",
                     help="enqueue all max_steps loop iterations per frame instead of (iterations seen in the warm-up + 2); "
                          "with the hint the device flags any frame it was too small for and the run is repeated without it")
@@ -75,7 +76,7 @@ GRID_XYZ_BYTES_PER_SAMPLE = 1024 + 12 + 128
 FUSED_BYTES_PER_SAMPLE = 1024 + 512 + 12 + 12 + 4 + 4 + 12
 MLP_FLOP_PER_SAMPLE = 56704          # 2 x 28352 MAC
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16/bf16 (v_mfma_f32_32x32x16_f16)
+MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16/bf16 peak (the K=16 forms; the kernels use K=8)
 
 
 def kernel_select(engine, acc):

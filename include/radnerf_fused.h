@@ -55,7 +55,7 @@ typedef struct {
 /* Number of floats of the packed (MFMA-ordered) weight image / of the per-frame bias block. */
 size_t rn_nerf_packed_floats(void);
 /* Opt-in 16-bit matrix-core variant (mlp_dtype = RN_F16 below): weights and per-sample activations are rounded to fp16
- * where they enter v_mfma_f32_32x32x16_f16, accumulation stays fp32 -- the arithmetic of the reference's `-O`
+ * where they enter the f16 matrix instruction (v_mfma_f32_32x32x8f16), accumulation stays fp32 -- the arithmetic of the reference's `-O`
  * (autocast) mode, nerf/utils.py:944.  Grid interpolation, per-frame bias vectors, the narrow output layers and the
  * activations stay fp32.  Its weight image has its own size and packer; `packed` passed to rn_nerf_fused_forward /
  * rn_head_iterate must be the image that matches `mlp_dtype` (RN_F32: rn_nerf_pack_weights). */
@@ -63,7 +63,7 @@ size_t rn_nerf_packed_floats_h16(void);
 int rn_nerf_pack_weights_h16(const rn_nerf_weights_t *w, float *packed, rn_stream_t stream);
 /* Split-precision variant (mlp_dtype = RN_F32_SPLIT): fp32-grade contractions on the 16-bit matrix cores.  Every operand
  * is carried as two fp16 numbers (hi = fp16(v), lo = fp16(v - hi): 22 significant bits) and a product is evaluated as
- * hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x16_f16 (~3e-7 relative per product).  It meets the
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x8f16 (~3e-7 relative per product).  It meets the
  * tolerances of the fp32-MFMA kernel against the fp32 oracle; it is NOT bit-identical to it. */
 #define RN_F32_SPLIT 2
 size_t rn_nerf_packed_floats_split(void);
