@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
     uint32_t M = p.M;
     if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
     const uint32_t n_tiles = (M + 63u) >> 6;
-    if (blockIdx.x * kWavesPerBlock >= n_tiles) return;  // nothing for this workgroup (uniform)
+    {
+        const TileSchedule w0(n_tiles, kWavesPerBlock, 0u);
+        if (w0.first >= w0.end) return;  // nothing for this workgroup (uniform)
+    }
 
     for (int i = threadIdx.x; i < kPacked / 4; i += kFusedThreads)
         reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
@@ -165,7 +168,8 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
     const int lane_off = h * 64 + j * 2;
     const float *bias_amb = lds + kPacked, *bias_sig = lds + kPacked + 64, *bias_col = lds + kPacked + 128;
 
-    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+    const TileSchedule sched(n_tiles, kWavesPerBlock, (uint32_t)wave);
+    for (uint32_t tile = sched.first; tile < sched.end; tile += sched.stride) {
         const uint32_t sample = tile * 64 + lane;
         bool live = sample < M;
         if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;

@@ -8,6 +8,10 @@
 
 #include "../../include/radnerf_fused.h"
 
+#ifndef RN_XCD_TILES
+#define RN_XCD_TILES 1
+#endif
+
 namespace rn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -109,6 +113,31 @@ struct LevelLds {
     uint32_t resolution, offset, rows;
 };
 
+
+// XCD-aware tile schedule.  Workgroups are dealt round-robin over the 8 XCDs (workgroup b lands on XCD b % 8; used for
+// speed only -- any placement gives the same results), and every XCD has its own 4 MB L2.  Samples arrive ray-ordered,
+// i.e. consecutive tiles are neighbouring pixels whose samples share most of their grid rows on the coarse and middle
+// levels.  Giving each XCD one CONTIGUOUS eighth of the tiles (a band of the image) instead of every eighth workgroup's
+// tiles keeps those shared rows in one L2 instead of fetching them into all eight.
+struct TileSchedule {
+    uint32_t first, end, stride;
+    __device__ __forceinline__ TileSchedule(uint32_t n_tiles, uint32_t waves_per_block, uint32_t wave) {
+        const uint32_t G = gridDim.x, b = blockIdx.x;
+#if RN_XCD_TILES
+        if (G >= 8 && (G & 7u) == 0) {
+            const uint32_t xcd = b & 7u, local = b >> 3, per_xcd = (n_tiles + 7u) >> 3;
+            const uint32_t lo = xcd * per_xcd, hi = lo + per_xcd < n_tiles ? lo + per_xcd : n_tiles;
+            first = lo + local * waves_per_block + wave;
+            end = lo < hi ? hi : lo;
+            stride = (G >> 3) * waves_per_block;
+            return;
+        }
+#endif
+        first = b * waves_per_block + wave;
+        end = n_tiles;
+        stride = G * waves_per_block;
+    }
+};
 
 // Launch of the f16-MFMA variant (rn_fused_h16.hip); `gx_dtype` / `gw_dtype` are the grid table dtypes.
 void launch_fused_h16(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t blocks, hipStream_t s);

@@ -164,7 +164,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
     uint32_t M = p.M;
     if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
     const uint32_t n_tiles = (M + 63u) >> 6;
-    if (blockIdx.x * kWavesPerBlock >= n_tiles) return;  // nothing for this workgroup (uniform)
+    {
+        const TileSchedule w0(n_tiles, kWavesPerBlock, 0u);
+        if (w0.first >= w0.end) return;  // nothing for this workgroup (uniform)
+    }
 
     for (int i = threadIdx.x; i < kHPacked / 4; i += kFusedThreads)
         reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
@@ -184,7 +187,8 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
     const float *bias_amb = lds + kHPacked, *bias_sig = lds + kHPacked + 64, *bias_col = lds + kHPacked + 128;
     uint32_t *stage = stage_all + wave * kStageWords;
 
-    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+    const TileSchedule sched(n_tiles, kWavesPerBlock, (uint32_t)wave);
+    for (uint32_t tile = sched.first; tile < sched.end; tile += sched.stride) {
         const uint32_t sample = tile * 64 + lane;
         bool live = sample < M;
         if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;

@@ -205,7 +205,10 @@ __global__ void __launch_bounds__(kX2Threads, 2) k_nerf_fused_x2(FusedParams p) 
     uint32_t M = p.M;
     if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
     const uint32_t n_tiles = (M + 63u) >> 6;
-    if (blockIdx.x * kX2Waves >= n_tiles) return;  // nothing for this workgroup (uniform)
+    {
+        const TileSchedule w0(n_tiles, kX2Waves, 0u);
+        if (w0.first >= w0.end) return;  // nothing for this workgroup (uniform)
+    }
 
     for (int i = threadIdx.x; i < kX2MfmaFloats / 4; i += kX2Threads)
         reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
@@ -225,7 +228,8 @@ __global__ void __launch_bounds__(kX2Threads, 2) k_nerf_fused_x2(FusedParams p) 
     const float *valu_w = p.packed;                                                        // narrow fp32 layers, global
     uint32_t *stage = stage_all + wave * kStageWords;
 
-    for (uint32_t tile = blockIdx.x * kX2Waves + wave; tile < n_tiles; tile += gridDim.x * kX2Waves) {
+    const TileSchedule sched(n_tiles, kX2Waves, (uint32_t)wave);
+    for (uint32_t tile = sched.first; tile < sched.end; tile += sched.stride) {
         const uint32_t sample = tile * 64 + lane;
         bool live = sample < M;
         if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;
