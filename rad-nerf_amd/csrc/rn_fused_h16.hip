@@ -16,6 +16,10 @@
 #include "rn_fused_dev.h"
 
 
+#ifndef RN_MFMA_K16
+#define RN_MFMA_K16 0
+#endif
+
 namespace rn {
 
 #ifndef RN_FUSED_PAIR_HASHED
@@ -91,7 +95,11 @@ __global__ void __launch_bounds__(256) k_pack_nerf_h16(RawW w, float *__restrict
 // K = 8 form below is bit-stable under the same conditions.  One 16-k step = two K = 8 instructions on elements
 // 0..3 and 4..7 of both fragments (any pairing that takes the same elements from A and B sums the same products);
 // the matrix pipe is far from binding in these kernels, so the 2x instruction count is not measurable.
+// (tools/repro_mfma_k16.sh rebuilds this file with -DRN_MFMA_K16=1 and runs tools/check_determinism.py to show it.)
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+#if RN_MFMA_K16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const f16x4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
     const f16x4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
