@@ -111,7 +111,11 @@ typedef struct {
 /* near/far + loop initialisation (rays_alive = arange(N), rays_t = nears, accumulators = 0, step = 0). */
 int rn_head_begin(const rn_head_t *h, rn_stream_t stream);
 /* Enqueue loop iterations first_iter .. first_iter + n_iters - 1.  Iterations past the end of the loop
- * (step >= max_steps or no ray alive) are no-ops decided on the device. */
+ * (step >= max_steps or no ray alive) are no-ops decided on the device.  Kernels per call: march(first_iter), then per
+ * iteration {fused network, composite, compaction}; inside a call the compaction kernel also marches the next iteration
+ * (3 launches per iteration), the last compaction of a call does not -- so a loop enqueued one iteration per call is the
+ * plain four-kernel sequence and its schedule may be adjusted between calls (rn_head_reschedule).  mlp_dtype selects the
+ * arithmetic variant of the network kernel (RN_F32 / RN_F32_SPLIT / RN_F16) and must match the packed image. */
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
                     const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream);
 /* Step schedule of a SHARD of a frame (tile-parallel rendering, BASELINE config 4).  The reference's policy
