@@ -138,9 +138,14 @@ class FrameParallelRenderer(_Bookkeeping):
     def step(self, step):
         self._advance_audio(skipped_frames(step, self.rank, self.world))
         g = frame_of(step, self.rank, self.world)
-        out = self.scene.render(g)
-        image = out["image"]
-        u8 = (image.reshape(self.scene.H, self.scene.W, 3) * 255).to(torch.uint8)
+        try:
+            out = self.scene.render(g, want_u8=True)
+        except TypeError:                      # a scene object without the want_u8 option
+            out = self.scene.render(g)
+        if "image_u8" in out:                  # quantised by the blend kernel itself
+            u8 = out["image_u8"].reshape(self.scene.H, self.scene.W, 3)
+        else:
+            u8 = (out["image"].reshape(self.scene.H, self.scene.W, 3) * 255).to(torch.uint8)
         if self.gather:
             if self.frames_u8 is None:
                 self.frames_u8 = torch.empty((self.world,) + tuple(u8.shape), dtype=torch.uint8, device=u8.device)

@@ -139,7 +139,11 @@ class SyntheticScene:
         o = self.opt
         return dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps, perturb=False, force_all_rays=True, T_thresh=1e-4)
 
-    def render(self, i):
+    def render(self, i, want_u8=False):
+        """want_u8: the fused engine's blend kernel also writes the quantised frame (out["image_u8"], SURVEY f-4)."""
         f = self.frame(i)
+        kw = self.render_kwargs()
+        if want_u8:
+            kw["want_u8"] = True
         return self.model.render(f["rays_o"], f["rays_d"], f["auds"], f["bg_coords"], f["poses"], eye=f["eye"],
-                                 index=f["index"], bg_color=f["bg_color"], **self.render_kwargs())
+                                 index=f["index"], bg_color=f["bg_color"], **kw)
