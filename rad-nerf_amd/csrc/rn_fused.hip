@@ -27,8 +27,15 @@
 namespace rn {
 
 #ifndef RN_FUSED_PAIR_HASHED
-#define RN_FUSED_PAIR_HASHED 1
+#define RN_FUSED_PAIR_HASHED 0
 #endif
+#ifndef RN_F32_XYZ_GROUP
+#define RN_F32_XYZ_GROUP 2
+#endif
+#ifndef RN_F32_AMB_GROUP
+#define RN_F32_AMB_GROUP 2
+#endif
+constexpr int kXyzGroup = RN_F32_XYZ_GROUP, kAmbGroup = RN_F32_AMB_GROUP;  // levels gathered per round (divide 16)
 constexpr bool kPairHashed = RN_FUSED_PAIR_HASHED;  // aligned x-pair loads on hashed levels inside the fused kernels
 
 // ---- packed weight image (floats) --------------------------------------------------------------------
@@ -139,10 +146,24 @@ __device__ __forceinline__ void level_features(const void *table, const LevelLds
     }
 }
 
+// -DRN_PHASE_CLOCK (tools/gpu_phase_clock.sh only): lanes 0..3 of every tile overwrite their `ambient` outputs with the
+// 100 MHz wall-clock ticks spent in the phases of the tile loop (xyz gather, ambient net, ambient gather, rest).
+#ifdef RN_PHASE_CLOCK
+#define RN_PHASE_MARK(i) const uint64_t phase_t##i = wall_clock64()
+#define RN_PHASE_STORE()                                                                                        \
+    if (p.ambient && lane < 2 && sample + 1 < M) {                                                              \
+        p.ambient[2 * (size_t)sample] = (float)(lane ? phase_t3 - phase_t2 : phase_t1 - phase_t0);                \
+        p.ambient[2 * (size_t)sample + 1] = (float)(lane ? phase_t4 - phase_t3 : phase_t2 - phase_t1);            \
+    }
+#else
+#define RN_PHASE_MARK(i)
+#define RN_PHASE_STORE()
+#endif
+
 template <typename TX, typename TW>
 __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
-    __shared__ LevelLds lvl_x[16], lvl_w[16];
+    __shared__ LevelPlan plan_x[16], plan_w[16];
 
     uint32_t M = p.M;
     if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
@@ -158,8 +179,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
     if (threadIdx.x < 16) {
         const int t = threadIdx.x;
         const uint32_t ox = (uint32_t)p.gx.offsets[t], ow = (uint32_t)p.gw.offsets[t];
-        lvl_x[t] = LevelLds{p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox};
-        lvl_w[t] = LevelLds{p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow};
+        plan_x[t] = plan_level<3>(p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox,
+                                  p.gx.gridtype, (uint32_t)sizeof(TX) * 2u);
+        plan_w[t] = plan_level<2>(p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow,
+                                  p.gw.gridtype, (uint32_t)sizeof(TW) * 2u);
     }
     __syncthreads();
 
@@ -179,6 +202,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
         // feature pair goes straight into MFMA step `l` of BOTH first layers that consume enc_x (ambient L0 and
         // sigma L0), so enc_x is never kept in registers.
         Acc a0, a1, a2;
+        RN_PHASE_MARK(0);
         acc_bias(a0, bias_amb, h);  // ambient L0 accumulators, start = W0[:, 32:] enc_a
         acc_bias(a2, bias_sig, h);  // sigma   L0 accumulators, start = W0[:, 64] eye
         {
@@ -191,37 +215,35 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                     on = on && !(in[d] < 0 || in[d] > 1);
                 }
             }
-            // One level at a time: the partner wave on the SIMD covers the load latency (a two-deep software pipeline
-            // was measured equal within noise and cost 19 spilled VGPRs = 4 MB of scratch writes per launch).
-            LevelFetch<TX, 3, 2> fa;
-            auto issue = [&](int l, LevelFetch<TX, 3, 2> &f) {
-                if (on) {
-                    const LevelLds lv = lvl_x[l];
-                    issue_level<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), lv.offset, in, lv.scale,
-                                          lv.resolution, lv.rows, p.gx.gridtype, false, 0, f);
-                }
-            };
-            auto consume = [&](int l, const LevelFetch<TX, 3, 2> &f) {
-                float f0 = 0.0f, f1 = 0.0f, b0, b1;
-                if (on) {
-                    TX res[2];
-                    TX dummy[1];
-                    blend_level<TX, 3, 2, false>(f, lvl_x[l].scale, res, dummy);
-                    f0 = to_f<TX>(res[0]);
-                    f1 = to_f<TX>(res[1]);
-                }
-                to_b_operands(f0, f1, b0, b1);
-                step64(a0, lds + OFF_A0, l, lane_off, b0, b1);
-                step64(a2, lds + OFF_S0, l, lane_off, b0, b1);
-            };
+            // kXyzGroup levels per round: their index arithmetic, loads and blends are independent chains that the
+            // scheduler interleaves (the gather is bound by the latency of one level's chain, not by memory).
+            LevelFetch<TX, 3, 2> f[kXyzGroup];
 #pragma unroll 1
-            for (int l = 0; l < 16; l++) {
-                issue(l, fa);
-                consume(l, fa);
+            for (int g = 0; g < 16; g += kXyzGroup) {
+                if (on) {
+#pragma unroll
+                    for (int i = 0; i < kXyzGroup; i++)
+                        issue_planned<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), plan_x[g + i], in, f[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < kXyzGroup; i++) {
+                    float f0 = 0.0f, f1 = 0.0f, b0, b1;
+                    if (on) {
+                        TX res[2];
+                        TX dummy[1];
+                        blend_level<TX, 3, 2, false>(f[i], 0.0f, res, dummy);
+                        f0 = to_f<TX>(res[0]);
+                        f1 = to_f<TX>(res[1]);
+                    }
+                    to_b_operands(f0, f1, b0, b1);
+                    step64(a0, lds + OFF_A0, g + i, lane_off, b0, b1);
+                    step64(a2, lds + OFF_S0, g + i, lane_off, b0, b1);
+                }
             }
         }
 
         // ---- ambient net: [enc_x | enc_a] 96 -> 64 -> 64 -> 2, tanh
+        RN_PHASE_MARK(1);
         acc_relu(a0);
         acc_zero(a1);
         layer_from_acc(a1, a0, lds + OFF_A1, lane_off);
@@ -239,37 +261,36 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
         }
 
         // ---- ambient grid: enc_w = encoder_ambient(ambient, bound=1) -> sigma L0 steps 16..31
+        RN_PHASE_MARK(2);
         {
             float in[2] = {(amb[0] + 1.0f) / 2.0f, (amb[1] + 1.0f) / 2.0f};
             const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
-            LevelFetch<TW, 2, 2> fa;
-            auto issue = [&](int l, LevelFetch<TW, 2, 2> &f) {
-                if (on) {
-                    const LevelLds lv = lvl_w[l];
-                    issue_level<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), lv.offset, in, lv.scale,
-                                          lv.resolution, lv.rows, p.gw.gridtype, false, 0, f);
-                }
-            };
-            auto consume = [&](int l, const LevelFetch<TW, 2, 2> &f) {
-                float f0 = 0.0f, f1 = 0.0f, b0, b1;
-                if (on) {
-                    TW res[2];
-                    TW dummy[1];
-                    blend_level<TW, 2, 2, false>(f, lvl_w[l].scale, res, dummy);
-                    f0 = to_f<TW>(res[0]);
-                    f1 = to_f<TW>(res[1]);
-                }
-                to_b_operands(f0, f1, b0, b1);
-                step64(a2, lds + OFF_S0, 16 + l, lane_off, b0, b1);
-            };
+            LevelFetch<TW, 2, 2> f[kAmbGroup];
 #pragma unroll 1
-            for (int l = 0; l < 16; l++) {
-                issue(l, fa);
-                consume(l, fa);
+            for (int g = 0; g < 16; g += kAmbGroup) {
+                if (on) {
+#pragma unroll
+                    for (int i = 0; i < kAmbGroup; i++)
+                        issue_planned<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), plan_w[g + i], in, f[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < kAmbGroup; i++) {
+                    float f0 = 0.0f, f1 = 0.0f, b0, b1;
+                    if (on) {
+                        TW res[2];
+                        TW dummy[1];
+                        blend_level<TW, 2, 2, false>(f[i], 0.0f, res, dummy);
+                        f0 = to_f<TW>(res[0]);
+                        f1 = to_f<TW>(res[1]);
+                    }
+                    to_b_operands(f0, f1, b0, b1);
+                    step64(a2, lds + OFF_S0, 16 + g + i, lane_off, b0, b1);
+                }
             }
         }
 
         // ---- sigma net: [enc_x | enc_w | eye] 65 -> 64 -> 64 -> 1 + 64
+        RN_PHASE_MARK(3);
         acc_relu(a2);
         acc_zero(a1);
         layer_from_acc(a1, a2, lds + OFF_S1, lane_off);
@@ -314,6 +335,8 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                 }
             }
         }
+        RN_PHASE_MARK(4);
+        RN_PHASE_STORE();
     }
 }
 

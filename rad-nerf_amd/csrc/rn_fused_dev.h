@@ -11,6 +11,9 @@
 #ifndef RN_XCD_TILES
 #define RN_XCD_TILES 1
 #endif
+#ifndef RN_TILE_CHUNK
+#define RN_TILE_CHUNK 8
+#endif
 
 namespace rn {
 
@@ -127,9 +130,15 @@ struct TileSchedule {
         if (G >= 8 && (G & 7u) == 0) {
             const uint32_t xcd = b & 7u, local = b >> 3, per_xcd = (n_tiles + 7u) >> 3;
             const uint32_t lo = xcd * per_xcd, hi = lo + per_xcd < n_tiles ? lo + per_xcd : n_tiles;
-            first = lo + local * waves_per_block + wave;
+            // Within the band, RN_TILE_CHUNK consecutive tiles go to one workgroup and the next chunk to the next
+            // workgroup; a workgroup's second chunk lands on its next RN_TILE_CHUNK waves.  A launch of the frame loop
+            // holds 1.0 - 2.0 tiles per wave slot of the chip, so what matters is that the tiles beyond one full round
+            // are spread over all CUs (chunk < waves per workgroup) instead of doubling up a few of them.
+            constexpr uint32_t C = RN_TILE_CHUNK;
+            const uint32_t chunk = C < waves_per_block ? C : waves_per_block, B = G >> 3;
+            first = lo + ((wave / chunk) * B + local) * chunk + wave % chunk;
             end = lo < hi ? hi : lo;
-            stride = (G >> 3) * waves_per_block;
+            stride = B * waves_per_block;
             return;
         }
 #endif

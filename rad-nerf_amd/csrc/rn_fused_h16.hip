@@ -167,7 +167,7 @@ template <typename TX, typename TW>
 __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kHPacked + kHBias];
     __shared__ __attribute__((aligned(16))) uint32_t stage_all[kWavesPerBlock * kStageWords];
-    __shared__ LevelLds lvl_x[16], lvl_w[16];
+    __shared__ LevelPlan plan_x[16], plan_w[16];
 
     uint32_t M = p.M;
     if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
     if (threadIdx.x < 16) {
         const int t = threadIdx.x;
         const uint32_t ox = (uint32_t)p.gx.offsets[t], ow = (uint32_t)p.gw.offsets[t];
-        lvl_x[t] = LevelLds{p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox};
-        lvl_w[t] = LevelLds{p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow};
+        plan_x[t] = plan_level<3>(p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox,
+                                  p.gx.gridtype, (uint32_t)sizeof(TX) * 2u);
+        plan_w[t] = plan_level<2>(p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow,
+                                  p.gw.gridtype, (uint32_t)sizeof(TW) * 2u);
     }
     __syncthreads();
 
@@ -219,9 +221,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
                 if (on) {
 #pragma unroll
                     for (int i = 0; i < kXyzGroup; i++) {
-                        const LevelLds lv = lvl_x[g + i];
-                        issue_level<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), lv.offset, in, lv.scale,
-                                              lv.resolution, lv.rows, p.gx.gridtype, false, 0, f[i]);
+                        issue_planned<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), plan_x[g + i], in, f[i]);
                     }
                 }
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
                     if (on) {
                         TX res[2];
                         TX dummy[1];
-                        blend_level<TX, 3, 2, false>(f[i], lvl_x[g + i].scale, res, dummy);
+                        blend_level<TX, 3, 2, false>(f[i], 0.0f, res, dummy);
                         pk = pack_h2(to_f<TX>(res[0]), to_f<TX>(res[1]));
                     }
                     stage[lane * kStageRow + g + i] = pk;
@@ -274,9 +274,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
                 if (on) {
 #pragma unroll
                     for (int i = 0; i < kAmbGroup; i++) {
-                        const LevelLds lv = lvl_w[g + i];
-                        issue_level<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), lv.offset, in, lv.scale,
-                                              lv.resolution, lv.rows, p.gw.gridtype, false, 0, f[i]);
+                        issue_planned<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), plan_w[g + i], in, f[i]);
                     }
                 }
 #pragma unroll
@@ -285,7 +283,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
                     if (on) {
                         TW res[2];
                         TW dummy[1];
-                        blend_level<TW, 2, 2, false>(f[i], lvl_w[g + i].scale, res, dummy);
+                        blend_level<TW, 2, 2, false>(f[i], 0.0f, res, dummy);
                         pk = pack_h2(to_f<TW>(res[0]), to_f<TW>(res[1]));
                     }
                     stage[lane * kStageRow + 16 + g + i] = pk;

@@ -90,6 +90,11 @@ struct RowWords {
 // turns into the scalar-base form of global_load (one offset VGPR per load instead of a 64-bit address pair).
 template <typename T, uint32_t C>
 __device__ __forceinline__ void load_row_words(const T *table, uint32_t byte_off, uint32_t (&w)[RowWords<T, C>::W]) {
+#ifdef RN_EXP_NO_LOADS  // experiment only (tools/gpu_phase_clock.sh): index arithmetic without the memory access
+#pragma unroll
+    for (uint32_t i = 0; i < RowWords<T, C>::W; i++) w[i] = byte_off + i;
+    return;
+#endif
     const char *p = reinterpret_cast<const char *>(table) + byte_off;
     constexpr uint32_t bytes = RowWords<T, C>::bytes;
     if constexpr (bytes == 2) {
@@ -113,6 +118,11 @@ __device__ __forceinline__ void load_row_words(const T *table, uint32_t byte_off
 template <typename T, uint32_t C>
 __device__ __forceinline__ void load_pair_words(const T *table, uint32_t byte_off, uint32_t (&a)[RowWords<T, C>::W],
                                                 uint32_t (&b)[RowWords<T, C>::W]) {
+#ifdef RN_EXP_NO_LOADS
+#pragma unroll
+    for (uint32_t i = 0; i < RowWords<T, C>::W; i++) a[i] = byte_off + i, b[i] = byte_off - i;
+    return;
+#endif
     const char *p = reinterpret_cast<const char *>(table) + byte_off;
     constexpr uint32_t bytes = RowWords<T, C>::bytes * 2;
     constexpr uint32_t words = bytes / 4;
@@ -289,6 +299,138 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, uint32_
                 load_row_words<T, C>(table, (level_row + row0) * kRowBytes, f.rows[idx]);
                 load_row_words<T, C>(table, (level_row + row1) * kRowBytes, f.rows[idx + 1]);
             }
+        }
+    }
+}
+
+// ---- planned levels ----------------------------------------------------------------------------------------------
+// The fused network kernels walk 32 levels per sample tile and are bound by instruction issue, not by memory, as long
+// as every level re-derives its wave-uniform facts (which dimensions are dense, hashed or not, power-of-two row count)
+// and pays a chain of branches per corner for the modulo.  A LevelPlan holds those facts, computed once per workgroup:
+//   row(corner) = combine(x, y * mult1, z * mult2) & mask           combine = + (dense / tiled)  or  ^ (hashed)
+// `mask` is size - 1 for a power-of-two row count (every capped level of the shipped configurations) and all-ones for a
+// dense level, whose index is always in range; any other level is "generic" and takes a real modulo.  Same integer
+// arithmetic as grid_row() / issue_level(), so the rows -- and with blend_level() the features -- are bit-identical.
+struct LevelPlan {
+    float scale;
+    uint32_t mult1, mult2;  // index multipliers of dimensions 1 and 2 (dimension 0: stride 1 and prime 1)
+    uint32_t mask;
+    uint32_t byte_base;     // first row of the level, in bytes
+    uint32_t size;          // row count (generic levels)
+    uint32_t mode;          // kPlanHashed | kPlanGeneric
+    uint32_t pad_;
+};
+constexpr uint32_t kPlanHashed = 1u, kPlanGeneric = 2u;
+
+template <uint32_t D>
+__device__ __forceinline__ LevelPlan plan_level(float scale, uint32_t resolution, uint32_t level_row, uint32_t size,
+                                                uint32_t gridtype, uint32_t row_bytes) {
+    static_assert(D == 2 || D == 3, "planned levels: 2-D and 3-D grids");
+    constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+    uint32_t mult[3] = {0u, 0u, 0u};
+    uint32_t stride = 1;
+    for (uint32_t d = 0; d < D; d++) {           // gridencoder.cu:66-84 with align_corners = false
+        if (stride <= size) {
+            mult[d] = stride;
+            stride *= resolution + 1;
+        }
+    }
+    const bool hashed = gridtype == 0 && stride > size;
+    if (hashed)
+        for (uint32_t d = 0; d < D; d++) mult[d] = primes[d];
+    const bool pow2 = (size & (size - 1u)) == 0u;
+    const bool in_range = !hashed && stride <= size;  // every dimension dense: index < (resolution + 1)^D <= size
+    LevelPlan lp;
+    lp.scale = scale;
+    lp.mult1 = mult[1];
+    lp.mult2 = mult[2];
+    lp.mask = pow2 ? size - 1u : 0xffffffffu;
+    lp.byte_base = level_row * row_bytes;
+    lp.size = size;
+    lp.mode = (hashed ? kPlanHashed : 0u) | ((pow2 || in_range) ? 0u : kPlanGeneric);
+    lp.pad_ = 0;
+    return lp;
+}
+
+// issue_level() for a planned level (align_corners = false, linear interpolation).  One wave-uniform branch picks the
+// level kind; inside, the 2^D loads sit in straight-line code.
+template <typename T, uint32_t D, uint32_t C, bool PAIR_HASHED = true>
+__device__ __forceinline__ void issue_planned(const T *__restrict__ table, const LevelPlan &lp, const float (&in)[D],
+                                              LevelFetch<T, D, C> &f) {
+    constexpr uint32_t kRowBytes = sizeof(T) * C;
+    constexpr bool kCanPair = kRowBytes * 2 <= 32;
+    constexpr uint32_t P = 1u << (D - 1);  // x-pairs of corners
+    uint32_t pg[D];
+    lattice_pos<D>(in, lp.scale, false, 0, f.pos, f.pos_deriv, pg);
+    uint32_t t0[D], t1[D];
+    t0[0] = pg[0];
+    t1[0] = pg[0] + 1u;
+    t0[1] = pg[1] * lp.mult1;
+    t1[1] = t0[1] + lp.mult1;
+    if constexpr (D == 3) {
+        t0[2] = pg[2] * lp.mult2;
+        t1[2] = t0[2] + lp.mult2;
+    }
+    f.swapped = 0;
+    const uint32_t mode = __builtin_amdgcn_readfirstlane(lp.mode);
+    const uint32_t mask = lp.mask, base_bytes = lp.byte_base;
+    if (mode == 0u) {
+        uint32_t r0[P];
+        bool wraps = false;
+#pragma unroll
+        for (uint32_t q = 0; q < P; q++) {
+            uint32_t base = t0[0];
+#pragma unroll
+            for (uint32_t d = 1; d < D; d++) base += ((q >> (d - 1)) & 1u) ? t1[d] : t0[d];
+            r0[q] = base & mask;
+            wraps = wraps || r0[q] == mask;   // then the x + 1 neighbour is row 0, not r0 + 1
+        }
+        if (kCanPair && __builtin_amdgcn_ballot_w64(wraps) == 0ull) {
+#pragma unroll
+            for (uint32_t q = 0; q < P; q++)
+                load_pair_words<T, C>(table, base_bytes + r0[q] * kRowBytes, f.rows[2 * q], f.rows[2 * q + 1]);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < P; q++) {
+                load_row_words<T, C>(table, base_bytes + r0[q] * kRowBytes, f.rows[2 * q]);
+                load_row_words<T, C>(table, base_bytes + ((r0[q] + 1u) & mask) * kRowBytes, f.rows[2 * q + 1]);
+            }
+        }
+    } else if (mode == kPlanHashed) {
+        uint32_t h[P];
+#pragma unroll
+        for (uint32_t q = 0; q < P; q++) {
+            h[q] = 0;
+#pragma unroll
+            for (uint32_t d = 1; d < D; d++) h[q] ^= ((q >> (d - 1)) & 1u) ? t1[d] : t0[d];
+        }
+        // x even: x ^ (x + 1) == 1, so the two x-neighbours of every pair are the halves of one aligned 2-row block
+        if (PAIR_HASHED && kCanPair && !(pg[0] & 1u)) {
+#pragma unroll
+            for (uint32_t q = 0; q < P; q++) {
+                const uint32_t row0 = (h[q] ^ t0[0]) & mask;
+                load_pair_words<T, C>(table, base_bytes + (row0 & ~1u) * kRowBytes, f.rows[2 * q], f.rows[2 * q + 1]);
+                f.swapped |= (row0 & 1u) << q;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < P; q++) {
+                load_row_words<T, C>(table, base_bytes + ((h[q] ^ t0[0]) & mask) * kRowBytes, f.rows[2 * q]);
+                load_row_words<T, C>(table, base_bytes + ((h[q] ^ t1[0]) & mask) * kRowBytes, f.rows[2 * q + 1]);
+            }
+        }
+    } else {
+        const uint32_t size = lp.size;
+        const bool hashed = mode & kPlanHashed;
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            uint32_t index = (idx & 1u) ? t1[0] : t0[0];
+#pragma unroll
+            for (uint32_t d = 1; d < D; d++) {
+                const uint32_t t = ((idx >> d) & 1u) ? t1[d] : t0[d];
+                index = hashed ? index ^ t : index + t;
+            }
+            load_row_words<T, C>(table, base_bytes + (index % size) * kRowBytes, f.rows[idx]);
         }
     }
 }

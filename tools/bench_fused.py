@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--grid", default="hash19")
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--sweep", default="", help="comma-separated sample counts instead of the two defaults")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -29,7 +30,7 @@ def main():
     m = scene.model
     rng = np.random.default_rng(0)
     out = {"tag": args.tag, "mlp": args.mlp, "grid": args.grid}
-    for M in (1 << 20, 206000):
+    for M in ([int(v) for v in args.sweep.split(',')] if args.sweep else (1 << 20, 206000)):
         x = torch.from_numpy(ray_points(M - M % 8, rng) * 2 - 1).cuda()
         M = x.shape[0]
         d = torch.nn.functional.normalize(torch.randn(M, 3, device="cuda"), dim=1)
