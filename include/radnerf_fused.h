@@ -106,6 +106,10 @@ typedef struct {
     float *sigmas, *rgbs;                 /* [N] [N,3] */
     int32_t *state;                       /* [RN_HEAD_STATE_INTS] */
     uint32_t *block_counts;               /* [3 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums x 2 */
+    uint32_t order_w;                     /* 0: alive list starts in ray order.  Image width W (rays are row-major pixels,
+                                             W % 8 == 0, N % W == 0, (N / W) % 8 == 0; otherwise treated as 0): the list
+                                             starts in 8 x 8 pixel blocks, so neighbouring samples share more grid rows.
+                                             Speed only -- rays are independent, every pixel is unchanged. */
 } rn_head_t;
 
 /* near/far + loop initialisation (rays_alive = arange(N), rays_t = nears, accumulators = 0, step = 0). */

@@ -33,9 +33,13 @@ namespace rn {
 #define RN_F32_XYZ_GROUP 2
 #endif
 #ifndef RN_F32_AMB_GROUP
-#define RN_F32_AMB_GROUP 2
+#define RN_F32_AMB_GROUP 4
 #endif
-constexpr int kXyzGroup = RN_F32_XYZ_GROUP, kAmbGroup = RN_F32_AMB_GROUP;  // levels gathered per round (divide 16)
+constexpr int kXyzGroup = RN_F32_XYZ_GROUP, kAmbGroup = RN_F32_AMB_GROUP;  // gather rounds in flight per wave (divide 8)
+#ifndef RN_F32_WAVES
+#define RN_F32_WAVES 8
+#endif
+constexpr int kF32Waves = RN_F32_WAVES, kF32Threads = kF32Waves * kWave;  // 3 waves per SIMD (accumulators: 3 x 32 VGPRs), one workgroup per CU
 constexpr bool kPairHashed = RN_FUSED_PAIR_HASHED;  // aligned x-pair loads on hashed levels inside the fused kernels
 
 // ---- packed weight image (floats) --------------------------------------------------------------------
@@ -65,6 +69,7 @@ __global__ void __launch_bounds__(256) k_pack_nerf(RawW w, float *__restrict__ p
         const int row = 32 * rt + j;
         int k;
         if (kind == 0) k = 2 * s + h;                                  // natural feature pairs
+        else if (kind == 3) k = 4 * (s >> 1) + 2 * h + (s & 1);       // gather rounds: half h holds level 2 (s / 2) + h, steps = its 2 features
         else if (kind == 1) k = kmap(s, h);                            // previous accumulators
         else k = (s < 8) ? 2 * s + h : 16 + kmap(s - 8, h);            // color L0: sh pairs then geo accumulators
         return src[row * ld + k];
@@ -73,10 +78,10 @@ __global__ void __launch_bounds__(256) k_pack_nerf(RawW w, float *__restrict__ p
         const int q0 = e - base, o = q0 / 64, h = (q0 % 64) / 32, q = q0 % 32;
         return src[o * 64 + 32 * (q >> 4) + rowmap(q & 15, h)];
     };
-    if (e < OFF_A1) v = mfma_elem(OFF_A0, w.amb_w0, ldA0, 0);
+    if (e < OFF_A1) v = mfma_elem(OFF_A0, w.amb_w0, ldA0, 3);
     else if (e < OFF_A2) v = mfma_elem(OFF_A1, w.amb_w1, 64, 1);
     else if (e < OFF_S0) v = valu_elem(OFF_A2, w.amb_w2);
-    else if (e < OFF_S1) v = mfma_elem(OFF_S0, w.sig_w0, ldS0, 0);
+    else if (e < OFF_S1) v = mfma_elem(OFF_S0, w.sig_w0, ldS0, 3);
     else if (e < OFF_S2) v = mfma_elem(OFF_S1, w.sig_w1, 64, 1);
     else if (e < OFF_S2R) v = mfma_elem(OFF_S2, w.sig_w2 + 64, 64, 1);  // rows 1..64 = geo_feat
     else if (e < OFF_C0) v = valu_elem(OFF_S2R, w.sig_w2);              // row 0 = sigma
@@ -105,9 +110,15 @@ __global__ void __launch_bounds__(kBias) k_frame_bias(RawW w, const float *__res
 
 // ---- MFMA helpers ---------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#ifdef RN_EXP_NO_MFMA  // experiment only: keep the data dependence, drop the matrix instruction
+    c[0] += a * b;
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
 }
 
+// ---- 64-sample tiles (two column tiles per wave): the torso kernel
 // one MFMA step of a 64-row layer: weights of step s from LDS, B operands b0 / b1 for the two column tiles
 __device__ __forceinline__ void step64(Acc &a, const float *wl, int s, int lane_off, float b0, float b1) {
     const float2 w = *reinterpret_cast<const float2 *>(wl + s * kStep + lane_off);
@@ -146,7 +157,68 @@ __device__ __forceinline__ void level_features(const void *table, const LevelLds
     }
 }
 
-// -DRN_PHASE_CLOCK (tools/gpu_phase_clock.sh only): lanes 0..3 of every tile overwrite their `ambient` outputs with the
+// ---- 32-sample tiles: the head kernel
+// Accumulators of one 64-row layer for the 32 samples of a tile: [row tile], row on the register index, sample on the lane.
+struct Acc32 {
+    f32x16 v[2];
+};
+
+__device__ __forceinline__ void acc_zero(Acc32 &a) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.v[rt][r] = 0.0f;
+}
+__device__ __forceinline__ void acc_bias(Acc32 &a, const float *bias64, int h) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias64 + 32 * rt + 8 * g + 4 * h);
+            a.v[rt][4 * g + 0] = b.x; a.v[rt][4 * g + 1] = b.y; a.v[rt][4 * g + 2] = b.z; a.v[rt][4 * g + 3] = b.w;
+        }
+}
+__device__ __forceinline__ void acc_relu(Acc32 &a) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.v[rt][r] = fmaxf(a.v[rt][r], 0.0f);
+}
+
+// one MFMA step of a 64-row layer: weights of step s from LDS (one float2 = both row tiles), B operand b
+__device__ __forceinline__ void step32(Acc32 &a, const float *wl, int s, int lane_off, float b) {
+    const float2 w = *reinterpret_cast<const float2 *>(wl + s * kStep + lane_off);
+    a.v[0] = mfma32(w.x, b, a.v[0]);
+    a.v[1] = mfma32(w.y, b, a.v[1]);
+}
+
+// 64 -> 64 layer whose input is the previous layer's accumulators (32 steps)
+__device__ __forceinline__ void layer_from_acc(Acc32 &out, const Acc32 &in, const float *wl, int lane_off) {
+#pragma unroll
+    for (int s = 0; s < 32; s++) step32(out, wl, s, lane_off, in.v[s >> 4][s & 15]);
+}
+
+// out[o] = sum_k in[k] * W[o][k]: each lane half sums the k's it holds, one cross-half shuffle adds the other half's
+template <int NOUT>
+__device__ __forceinline__ void valu_out(const Acc32 &in, const float *wl, int h, float (&out)[NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) {
+        float p = 0.0f;
+        const float *wo = wl + (o * 2 + h) * 32;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const float4 w = *reinterpret_cast<const float4 *>(wo + 4 * g);
+            const int rt = g >> 2, r = (g & 3) * 4;
+            p = __builtin_fmaf(in.v[rt][r + 0], w.x, p);
+            p = __builtin_fmaf(in.v[rt][r + 1], w.y, p);
+            p = __builtin_fmaf(in.v[rt][r + 2], w.z, p);
+            p = __builtin_fmaf(in.v[rt][r + 3], w.w, p);
+        }
+        out[o] = p + __shfl_xor(p, 32, 64);
+    }
+}
+
+// -DRN_PHASE_CLOCK (tools/gpu_phase_clock.sh only): lanes 0..1 of every tile overwrite their `ambient` outputs with the
 // 100 MHz wall-clock ticks spent in the phases of the tile loop (xyz gather, ambient net, ambient gather, rest).
 #ifdef RN_PHASE_CLOCK
 #define RN_PHASE_MARK(i) const uint64_t phase_t##i = wall_clock64()
@@ -161,19 +233,19 @@ __device__ __forceinline__ void level_features(const void *table, const LevelLds
 #endif
 
 template <typename TX, typename TW>
-__global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) {
+__global__ void __launch_bounds__(kF32Threads, kF32Waves / 4) k_nerf_fused(FusedParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     __shared__ LevelPlan plan_x[16], plan_w[16];
 
     uint32_t M = p.M;
     if (p.m_dev) { const uint32_t d = (uint32_t)*p.m_dev; M = d < M ? d : M; }
-    const uint32_t n_tiles = (M + 63u) >> 6;
+    const uint32_t n_tiles = (M + 31u) >> 5;
     {
-        const TileSchedule w0(n_tiles, kWavesPerBlock, 0u);
+        const TileSchedule w0(n_tiles, kF32Waves, 0u);
         if (w0.first >= w0.end) return;  // nothing for this workgroup (uniform)
     }
 
-    for (int i = threadIdx.x; i < kPacked / 4; i += kFusedThreads)
+    for (int i = threadIdx.x; i < kPacked / 4; i += kF32Threads)
         reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.packed)[i];
     if (threadIdx.x < kBias) lds[kPacked + threadIdx.x] = p.bias[threadIdx.x];
     if (threadIdx.x < 16) {
@@ -191,17 +263,17 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
     const int lane_off = h * 64 + j * 2;
     const float *bias_amb = lds + kPacked, *bias_sig = lds + kPacked + 64, *bias_col = lds + kPacked + 128;
 
-    const TileSchedule sched(n_tiles, kWavesPerBlock, (uint32_t)wave);
+    const TileSchedule sched(n_tiles, kF32Waves, (uint32_t)wave);
     for (uint32_t tile = sched.first; tile < sched.end; tile += sched.stride) {
-        const uint32_t sample = tile * 64 + lane;
+        const uint32_t sample = tile * 32 + j;  // both lane halves work on the same 32 samples
         bool live = sample < M;
         if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;
         if (__ballot(live) == 0ull) continue;  // whole tile dead (wave-uniform)
 
-        // ---- xyz grid, one sample per lane (gridencoder/grid.py:145-161: (x + bound) / (2 bound)).  Each level's
-        // feature pair goes straight into MFMA step `l` of BOTH first layers that consume enc_x (ambient L0 and
-        // sigma L0), so enc_x is never kept in registers.
-        Acc a0, a1, a2;
+        // ---- xyz grid (gridencoder/grid.py:145-161: (x + bound) / (2 bound)).  Round r: lane half h gathers level
+        // 2 r + h of its sample; the two features are the B operands of two MFMA steps of BOTH first layers that
+        // consume enc_x (ambient L0 and sigma L0), so enc_x is never kept in registers.
+        Acc32 a0, a1, a2;
         RN_PHASE_MARK(0);
         acc_bias(a0, bias_amb, h);  // ambient L0 accumulators, start = W0[:, 32:] enc_a
         acc_bias(a2, bias_sig, h);  // sigma   L0 accumulators, start = W0[:, 64] eye
@@ -215,19 +287,18 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                     on = on && !(in[d] < 0 || in[d] > 1);
                 }
             }
-            // kXyzGroup levels per round: their index arithmetic, loads and blends are independent chains that the
-            // scheduler interleaves (the gather is bound by the latency of one level's chain, not by memory).
+            // kXyzGroup rounds in flight: independent chains (index arithmetic, loads, blends) that hide each other's latency
             LevelFetch<TX, 3, 2> f[kXyzGroup];
 #pragma unroll 1
-            for (int g = 0; g < 16; g += kXyzGroup) {
+            for (int r = 0; r < 8; r += kXyzGroup) {
                 if (on) {
 #pragma unroll
                     for (int i = 0; i < kXyzGroup; i++)
-                        issue_planned<TX, 3, 2, kPairHashed>(static_cast<const TX *>(p.gx.table), plan_x[g + i], in, f[i]);
+                        issue_planned<TX, 3, 2, kPairHashed, false>(static_cast<const TX *>(p.gx.table), plan_x[2 * (r + i) + h], in, f[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < kXyzGroup; i++) {
-                    float f0 = 0.0f, f1 = 0.0f, b0, b1;
+                    float f0 = 0.0f, f1 = 0.0f;
                     if (on) {
                         TX res[2];
                         TX dummy[1];
@@ -235,9 +306,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                         f0 = to_f<TX>(res[0]);
                         f1 = to_f<TX>(res[1]);
                     }
-                    to_b_operands(f0, f1, b0, b1);
-                    step64(a0, lds + OFF_A0, g + i, lane_off, b0, b1);
-                    step64(a2, lds + OFF_S0, g + i, lane_off, b0, b1);
+                    step32(a0, lds + OFF_A0, 2 * (r + i), lane_off, f0);
+                    step32(a2, lds + OFF_S0, 2 * (r + i), lane_off, f0);
+                    step32(a0, lds + OFF_A0, 2 * (r + i) + 1, lane_off, f1);
+                    step32(a2, lds + OFF_S0, 2 * (r + i) + 1, lane_off, f1);
                 }
             }
         }
@@ -249,13 +321,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
         layer_from_acc(a1, a0, lds + OFF_A1, lane_off);
         acc_relu(a1);
         float amb[2];
-        {
-            float part[2][2];
-            valu_out<2>(a1, lds + OFF_A2, h, part);
-            amb[0] = tanhf(h ? part[1][0] : part[0][0]);
-            amb[1] = tanhf(h ? part[1][1] : part[0][1]);
-        }
-        if (p.ambient && live) {
+        valu_out<2>(a1, lds + OFF_A2, h, amb);
+        amb[0] = tanhf(amb[0]);
+        amb[1] = tanhf(amb[1]);
+        if (p.ambient && live && h == 0) {
             p.ambient[2 * (size_t)sample] = amb[0];
             p.ambient[2 * (size_t)sample + 1] = amb[1];
         }
@@ -267,15 +336,15 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
             const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
             LevelFetch<TW, 2, 2> f[kAmbGroup];
 #pragma unroll 1
-            for (int g = 0; g < 16; g += kAmbGroup) {
+            for (int r = 0; r < 8; r += kAmbGroup) {
                 if (on) {
 #pragma unroll
                     for (int i = 0; i < kAmbGroup; i++)
-                        issue_planned<TW, 2, 2, kPairHashed>(static_cast<const TW *>(p.gw.table), plan_w[g + i], in, f[i]);
+                        issue_planned<TW, 2, 2, kPairHashed, false>(static_cast<const TW *>(p.gw.table), plan_w[2 * (r + i) + h], in, f[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < kAmbGroup; i++) {
-                    float f0 = 0.0f, f1 = 0.0f, b0, b1;
+                    float f0 = 0.0f, f1 = 0.0f;
                     if (on) {
                         TW res[2];
                         TW dummy[1];
@@ -283,8 +352,8 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
                         f0 = to_f<TW>(res[0]);
                         f1 = to_f<TW>(res[1]);
                     }
-                    to_b_operands(f0, f1, b0, b1);
-                    step64(a2, lds + OFF_S0, 16 + g + i, lane_off, b0, b1);
+                    step32(a2, lds + OFF_S0, 16 + 2 * (r + i), lane_off, f0);
+                    step32(a2, lds + OFF_S0, 16 + 2 * (r + i) + 1, lane_off, f1);
                 }
             }
         }
@@ -297,9 +366,9 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
         acc_relu(a1);
         float sigma;
         {
-            float part[2][1];
-            valu_out<1>(a1, lds + OFF_S2R, h, part);
-            sigma = expf(h ? part[1][0] : part[0][0]);  // trunc_exp forward (activation.py:9-11)
+            float raw[1];
+            valu_out<1>(a1, lds + OFF_S2R, h, raw);
+            sigma = expf(raw[0]);  // trunc_exp forward (activation.py:9-11)
         }
         acc_zero(a0);
         layer_from_acc(a0, a1, lds + OFF_S2, lane_off);  // geo_feat (no activation)
@@ -315,24 +384,23 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused(FusedParams p) 
             sh_basis<4>(dx, dy, dz, sh);
 #pragma unroll
             for (int s = 0; s < 8; s++) {
-                float b0, b1;
-                to_b_operands(sh[2 * s], sh[2 * s + 1], b0, b1);
-                step64(a1, lds + OFF_C0, s, lane_off, b0, b1);
+                // lane half h supplies k = 2 s + h; a bit-select, because ?: on two array elements makes the compiler
+                // index sh[] dynamically and move it to LDS
+                const uint32_t m = 0u - (uint32_t)h;
+                const uint32_t b = (__float_as_uint(sh[2 * s]) & ~m) | (__float_as_uint(sh[2 * s + 1]) & m);
+                step32(a1, lds + OFF_C0, s, lane_off, __uint_as_float(b));
             }
         }
 #pragma unroll
-        for (int s = 0; s < 32; s++) step64(a1, lds + OFF_C0, 8 + s, lane_off, a0.v[0][s >> 4][s & 15], a0.v[1][s >> 4][s & 15]);
+        for (int s = 0; s < 32; s++) step32(a1, lds + OFF_C0, 8 + s, lane_off, a0.v[s >> 4][s & 15]);
         acc_relu(a1);
         {
-            float part[2][3];
-            valu_out<3>(a1, lds + OFF_C1, h, part);
-            if (live) {
+            float rgb[3];
+            valu_out<3>(a1, lds + OFF_C1, h, rgb);
+            if (live && h == 0) {
                 p.sigmas[sample] = sigma;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float x = h ? part[1][c] : part[0][c];
-                    p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-x));
-                }
+                for (int c = 0; c < 3; c++) p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-rgb[c]));
             }
         }
         RN_PHASE_MARK(4);
@@ -370,7 +438,8 @@ __global__ void __launch_bounds__(kLoopBlock)
 k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
              uint32_t N, float min_near, uint32_t max_steps, float *__restrict__ nears, float *__restrict__ fars,
              float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
-             int32_t *__restrict__ rays_alive, float *__restrict__ rays_t, int32_t *__restrict__ state) {
+             int32_t *__restrict__ rays_alive, float *__restrict__ rays_t, int32_t *__restrict__ state,
+             uint32_t order_w) {
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     if (n == 0) {
         next_state(state, N, N, 0, max_steps);
@@ -401,7 +470,15 @@ k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     far = miss ? FLT_MAX : far;
     nears[n] = near; fars[n] = far;
     rays_t[n] = near;
-    rays_alive[n] = (int32_t)n;
+    // Slot n of the alive list: ray n, or (order_w = image width) the rays of 8 x 8 pixel blocks together, so that the 64
+    // samples of a wave and the tiles of a CU cover a compact patch of the image instead of a one-pixel-high strip --
+    // more of their grid rows coincide.  Rays are independent, so the order changes no pixel.
+    uint32_t ray = n;
+    if (order_w) {
+        const uint32_t t = n >> 6, within = n & 63u, tiles_x = order_w >> 3;
+        ray = ((t / tiles_x) * 8u + (within >> 3)) * order_w + (t % tiles_x) * 8u + (within & 7u);
+    }
+    rays_alive[n] = (int32_t)ray;
     weights_sum[n] = 0.0f; depth[n] = 0.0f;
     image[n * 3] = 0.0f; image[n * 3 + 1] = 0.0f; image[n * 3 + 2] = 0.0f;
 }
@@ -916,11 +993,11 @@ static int num_cus() {
 
 template <typename TX, typename TW>
 static void launch_fused(const FusedParams &p, hipStream_t s) {
-    const uint32_t n_tiles = (p.M + 63u) >> 6;
-    uint32_t blocks = div_up(n_tiles, kWavesPerBlock);
+    const uint32_t n_tiles = (p.M + 31u) >> 5;
+    uint32_t blocks = div_up(n_tiles, kF32Waves);
     const uint32_t cap = (uint32_t)num_cus();  // one persistent workgroup per CU (96.5 KB of LDS each)
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_nerf_fused<TX, TW>), dim3(blocks), dim3(kFusedThreads), 0, s, p);
+    hipLaunchKernelGGL((k_nerf_fused<TX, TW>), dim3(blocks), dim3(kF32Threads), 0, s, p);
 }
 
 static int run_fused(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
@@ -1013,9 +1090,11 @@ static int check_head(const rn_head_t *h) {
 
 int rn_head_begin(const rn_head_t *h, rn_stream_t stream) {
     if (int rc = check_head(h)) return rc;
+    uint32_t order_w = h->order_w;
+    if (order_w && (order_w % 8u || h->N % order_w || (h->N / order_w) % 8u)) order_w = 0;
     hipLaunchKernelGGL(k_head_begin, dim3(div_up(h->N, kLoopBlock)), dim3(kLoopBlock), 0, as_stream(stream), h->rays_o,
                        h->rays_d, h->aabb, h->N, h->min_near, h->max_steps, h->nears, h->fars, h->weights_sum, h->depth,
-                       h->image, h->rays_alive_a, h->rays_t, h->state);
+                       h->image, h->rays_alive_a, h->rays_t, h->state, order_w);
     return check_launch("head_begin");
 }
 

@@ -135,7 +135,7 @@ struct TileSchedule {
             // holds 1.0 - 2.0 tiles per wave slot of the chip, so what matters is that the tiles beyond one full round
             // are spread over all CUs (chunk < waves per workgroup) instead of doubling up a few of them.
             constexpr uint32_t C = RN_TILE_CHUNK;
-            const uint32_t chunk = C < waves_per_block ? C : waves_per_block, B = G >> 3;
+            const uint32_t chunk = (C < waves_per_block && waves_per_block % C == 0) ? C : waves_per_block, B = G >> 3;
             first = lo + ((wave / chunk) * B + local) * chunk + wave % chunk;
             end = lo < hi ? hi : lo;
             stride = B * waves_per_block;

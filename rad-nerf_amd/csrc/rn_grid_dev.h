@@ -354,7 +354,9 @@ __device__ __forceinline__ LevelPlan plan_level(float scale, uint32_t resolution
 
 // issue_level() for a planned level (align_corners = false, linear interpolation).  One wave-uniform branch picks the
 // level kind; inside, the 2^D loads sit in straight-line code.
-template <typename T, uint32_t D, uint32_t C, bool PAIR_HASHED = true>
+// UNIFORM: every lane of the wave passes the same plan (one scalar branch); otherwise the level kind is a per-lane branch
+// (the 32-sample-tile kernel gives its two lane halves two different levels).
+template <typename T, uint32_t D, uint32_t C, bool PAIR_HASHED = true, bool UNIFORM = true>
 __device__ __forceinline__ void issue_planned(const T *__restrict__ table, const LevelPlan &lp, const float (&in)[D],
                                               LevelFetch<T, D, C> &f) {
     constexpr uint32_t kRowBytes = sizeof(T) * C;
@@ -372,7 +374,7 @@ __device__ __forceinline__ void issue_planned(const T *__restrict__ table, const
         t1[2] = t0[2] + lp.mult2;
     }
     f.swapped = 0;
-    const uint32_t mode = __builtin_amdgcn_readfirstlane(lp.mode);
+    const uint32_t mode = UNIFORM ? __builtin_amdgcn_readfirstlane(lp.mode) : lp.mode;
     const uint32_t mask = lp.mask, base_bytes = lp.byte_base;
     if (mode == 0u) {
         uint32_t r0[P];

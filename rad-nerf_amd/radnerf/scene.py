@@ -101,6 +101,7 @@ class SyntheticScene:
             model = NeRFNetwork(self.opt)
         init_synthetic_state(model, self.opt, seed, semi_axes, embedding_range)
         self.model = model.to(self.device).eval()
+        self.model.ray_order_width = W   # rays handed out below are row-major pixels (hint for the fused engine's loop order)
 
         # pose stream: OrbitCamera, yaw 8 deg * sin(2 pi t / 4 s), pitch 4 deg * sin(2 pi t / 2.5 s), 25 FPS
         self.intrinsics = intrinsics_from_fovy(H, W, self.opt.fovy)

@@ -343,3 +343,20 @@ def test_frame_parallel_renderer_learns_the_loop_length(hiplib):
         fpr.finish()                                   # would raise LoopHintTooSmall
     for g, w in zip(got, want):
         assert torch.equal(g, (w.reshape(64, 64, 3) * 255).to(torch.uint8))
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f32x2", "f16"])
+def test_block_ray_order_changes_no_pixel(hiplib, mlp):
+    """rn_head_t.order_w (8 x 8 pixel blocks in the alive list) is a speed knob: rays are independent, so image, depth and
+    the loop statistics are identical to the plain ray order -- bit for bit.  Also: a width the frame does not fit is ignored."""
+    outs = []
+    for width in (0, 64, 48):                 # 48: N / width is not an integer -> treated as 0
+        scene = _scene(64, "fused", mlp_dtype=mlp)
+        scene.model.ray_order_width = width
+        with torch.no_grad():
+            out = scene.render(1)
+        outs.append((out["image"].clone(), out["depth"].clone(), dict(scene.model.last_stats)))
+    for img, dep, st in outs[1:]:
+        assert torch.equal(img, outs[0][0])
+        assert torch.equal(torch.nan_to_num(dep, nan=-1.0), torch.nan_to_num(outs[0][1], nan=-1.0))
+        assert st == outs[0][2]

@@ -28,7 +28,7 @@ def main():
             for _ in range(3):
                 _, _, amb = fused.network_forward(m, x, d, enc_a, c, eye, want_ambient=True)
             torch.cuda.synchronize()
-            a = amb.view(-1, 64, 2)[: M // 64].cpu().numpy() / 100.0  # us
+            a = amb.view(-1, 32, 2)[: M // 32].cpu().numpy() / 100.0  # us
             ph = [a[:, 0, 0], a[:, 0, 1], a[:, 1, 0], a[:, 1, 1]]
             print(grid, "M", M, "per-tile us  xyz-gather %.1f  ambient-net %.1f  ambient-gather %.1f  sigma+color %.1f   (p90 %s)" % (
                 *[float(np.median(v)) for v in ph], " ".join("%.1f" % np.percentile(v, 90) for v in ph)), flush=True)
