@@ -141,17 +141,18 @@ __device__ __forceinline__ void to_b_operands(float f0, float f1, float &b0, flo
     b1 = __uint_as_float(r[1]);
 }
 
-// Features (2 channels) of one sample at one level; zeros when `on` is false.
+// Features (2 channels) of one sample at one planned level; zeros when `on` is false.
 template <typename TT, uint32_t D>
-__device__ __forceinline__ void level_features(const void *table, const LevelLds &lv, uint32_t gridtype,
-                                               const float (&in)[D], bool on, float &f0, float &f1) {
+__device__ __forceinline__ void level_features(const void *table, const LevelPlan &lp, const float (&in)[D], bool on,
+                                               float &f0, float &f1) {
     f0 = 0.0f;
     f1 = 0.0f;
     if (on) {
+        LevelFetch<TT, D, 2> f;
+        issue_planned<TT, D, 2, false>(static_cast<const TT *>(table), lp, in, f);
         TT res[2];
         TT dummy[1];
-        encode_level<TT, D, 2, false>(static_cast<const TT *>(table), lv.offset, in, lv.scale, lv.resolution,
-                                      lv.rows, gridtype, false, 0, res, dummy);
+        blend_level<TT, D, 2, false>(f, 0.0f, res, dummy);
         f0 = to_f<TT>(res[0]);
         f1 = to_f<TT>(res[1]);
     }
@@ -775,12 +776,13 @@ __device__ __forceinline__ float sample_torso_grid(const float *__restrict__ img
 template <typename TT>
 __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kTorsoPacked + kTorsoBias + 64];
-    __shared__ LevelLds lvl_t[16];
+    __shared__ LevelPlan plan_t[16];
     float *bias_def = lds + kTorsoPacked, *bias_tor = bias_def + 64, *enc_pose = bias_tor + 32;
     if (threadIdx.x >= 64 && threadIdx.x < 80) {
         const int t = threadIdx.x - 64;
         const uint32_t o = (uint32_t)p.gt.offsets[t];
-        lvl_t[t] = LevelLds{p.gt.lc.scale[t], p.gt.lc.resolution[t], o, (uint32_t)p.gt.offsets[t + 1] - o};
+        plan_t[t] = plan_level<2>(p.gt.lc.scale[t], p.gt.lc.resolution[t], o, (uint32_t)p.gt.offsets[t + 1] - o, p.gt.gridtype,
+                                  (uint32_t)sizeof(TT) * 2u);
     }
 
     for (int i = threadIdx.x; i < kTorsoPacked / 4; i += kFusedThreads)
@@ -879,7 +881,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p)
 #pragma unroll
             for (int l = 0; l < 16; l++) {
                 float f0, f1;
-                level_features<TT, 2>(p.gt.table, lvl_t[l], p.gt.gridtype, in, ok, f0, f1);
+                level_features<TT, 2>(p.gt.table, plan_t[l], in, ok, f0, f1);
                 to_b_operands(f0, f1, bg_[0][l], bg_[1][l]);
             }
         }

@@ -12,7 +12,7 @@
 #define RN_XCD_TILES 1
 #endif
 #ifndef RN_TILE_CHUNK
-#define RN_TILE_CHUNK 8
+#define RN_TILE_CHUNK 2
 #endif
 
 namespace rn {
@@ -108,14 +108,6 @@ struct FusedParams {
     float bound;
     float *sigmas, *rgbs, *ambient;
 };
-
-// Per-level constants staged in LDS so that the level loops can stay rolled (a by-value kernel argument
-// indexed at run time would be copied to scratch).
-struct LevelLds {
-    float scale;
-    uint32_t resolution, offset, rows;
-};
-
 
 // XCD-aware tile schedule.  Workgroups are dealt round-robin over the 8 XCDs (workgroup b lands on XCD b % 8; used for
 // speed only -- any placement gives the same results), and every XCD has its own 4 MB L2.  Samples arrive ray-ordered,

@@ -23,7 +23,7 @@
 namespace rn {
 
 #ifndef RN_FUSED_PAIR_HASHED
-#define RN_FUSED_PAIR_HASHED 1
+#define RN_FUSED_PAIR_HASHED 0
 #endif
 constexpr bool kPairHashed = RN_FUSED_PAIR_HASHED;  // aligned x-pair loads on hashed levels inside the fused kernels
 
@@ -155,12 +155,12 @@ __device__ __forceinline__ void stage_sync() {
 }
 
 #ifndef RN_XYZ_GROUP
-#define RN_XYZ_GROUP 1
+#define RN_XYZ_GROUP 2
 #endif
 #ifndef RN_AMB_GROUP
 #define RN_AMB_GROUP 4
 #endif
-constexpr int kXyzGroup = RN_XYZ_GROUP;  // xyz levels fetched together; measured 1 / 2 / 4: one is best (hash19 -6 %), the partner wave covers
+constexpr int kXyzGroup = RN_XYZ_GROUP;  // xyz levels fetched together; measured with planned levels, hash19: 2 is best (+1.5 % over 1; 4: -6 %)
 constexpr int kAmbGroup = RN_AMB_GROUP;  // ambient-grid levels fetched together (each: 8 row words + 3)
 
 template <typename TX, typename TW>

@@ -18,7 +18,7 @@
 namespace rn {
 
 #ifndef RN_FUSED_PAIR_HASHED
-#define RN_FUSED_PAIR_HASHED 1
+#define RN_FUSED_PAIR_HASHED 0
 #endif
 constexpr bool kPairHashedX2 = RN_FUSED_PAIR_HASHED;
 
