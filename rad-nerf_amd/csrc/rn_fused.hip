@@ -183,7 +183,7 @@ __device__ __forceinline__ void acc_relu(Acc32 &a) {
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) a.v[rt][r] = fmaxf(a.v[rt][r], 0.0f);
+        for (int r = 0; r < 16; r++) a.v[rt][r] = relu_bits(a.v[rt][r]);
 }
 
 // one MFMA step of a 64-row layer: weights of step s from LDS (one float2 = both row tiles), B operand b

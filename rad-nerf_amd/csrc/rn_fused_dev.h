@@ -60,13 +60,20 @@ __device__ __forceinline__ void acc_bias(Acc &a, const float *bias64, int h) {
         }
 }
 
+// max(x, 0) as ONE v_max_i32 on the bit pattern (a non-negative float is a non-negative integer, a negative one a negative
+// integer); fmaxf(x, 0) costs two VALU instructions because IEEE mode first quiets a possible signalling NaN.
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ void acc_relu(Acc &a) {
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = fmaxf(a.v[nt][rt][r], 0.0f);
+            for (int r = 0; r < 16; r++) a.v[nt][rt][r] = relu_bits(a.v[nt][rt][r]);
 }
 
 
