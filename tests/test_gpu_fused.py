@@ -360,3 +360,45 @@ def test_block_ray_order_changes_no_pixel(hiplib, mlp):
         assert torch.equal(img, outs[0][0])
         assert torch.equal(torch.nan_to_num(dep, nan=-1.0), torch.nan_to_num(outs[0][1], nan=-1.0))
         assert st == outs[0][2]
+
+
+def _recap_levels(enc, cap, seed):
+    """Give every level of a GridEncoder at most `cap` rows (a multiple of 8 that is NOT a power of two) and re-draw the table:
+    capped levels then need a true `index % rows` -- the "generic" level kind of the fused kernels' plans."""
+    D = enc.input_dim
+    S, H = float(np.log2(enc.per_level_scale)), enc.base_resolution
+    offs = [0]
+    for l in range(enc.num_levels):
+        res = int(np.ceil(np.exp2(l * S) * H - 1.0)) + 1
+        rows = min(cap, (res + 1) ** D)
+        offs.append(offs[-1] + int(np.ceil(rows / 8) * 8))
+    enc.offsets = torch.tensor(offs, dtype=enc.offsets.dtype, device=enc.offsets.device)
+    g = torch.Generator().manual_seed(seed)
+    enc.embeddings = torch.nn.Parameter(((torch.rand(offs[-1], enc.level_dim, generator=g) * 2 - 1) * 0.5).to(enc.offsets.device))
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f32x2"])
+@pytest.mark.parametrize("grid", ["hashgrid", "tiledgrid"])
+def test_fused_network_with_non_power_of_two_levels(po, hiplib, grid, mlp):
+    """Row counts that are neither dense nor a power of two (not produced by the reference's own offsets, but legal for the
+    C ABI): hashed AND tiled levels go through the plans' generic modulo and still match the oracle's `index % rows`."""
+    from radnerf import fused
+    scene = _scene(16, "fused", mlp_dtype=mlp, xyz_grid=grid, xyz_log2_hashmap_size=17)
+    m = scene.model
+    _recap_levels(m.encoder, 50000, 1)
+    _recap_levels(m.encoder_ambient, 3000, 2)
+    rng = np.random.default_rng(23)
+    M = 6007
+    x = rng.uniform(-0.9, 0.9, (M, 3)).astype(np.float32)
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    enc_a = rng.standard_normal((1, 64)).astype(np.float32)
+    eye = np.array([[0.4]], np.float32)
+    c = m.individual_codes[1].detach()
+    with torch.no_grad():
+        sigma, color, amb = fused.network_forward(m, torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(),
+                                                  torch.from_numpy(enc_a).cuda(), c, torch.from_numpy(eye).cuda())
+    es, ec, ea = po.nerf_forward(po.model_from_module(m), x, d, enc_a, c.cpu().numpy(), eye)
+    np.testing.assert_allclose(amb.cpu().numpy(), ea, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), es, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(color.cpu().numpy(), ec, rtol=0, atol=2e-5)
