@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-loop-hint", action="store_true",
                     help="enqueue all max_steps loop iterations per frame instead of (iterations seen in the warm-up + 2); "
                          "with the hint the device flags any frame it was too small for and the run is repeated without it")
+    ap.add_argument("--regime", default="B", choices=["A", "B"],
+                    help="SURVEY 8(d): B = worst case (sigma ~ 1, no ray terminates on opacity; default, headline), "
+                         "A = opaque (sigma scaled up x40: early termination active)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -215,6 +218,9 @@ def main():
     n_frames = 250
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
                            opt=default_opt(engine=engine, mlp_dtype=args.mlp, **GRIDS[args.grid]))
+    if args.regime == "A":
+        with torch.no_grad():
+            scene.model.sigma_net.net[-1].weight[0].abs_().mul_(40.0)
     tile = args.workload == "tile"
     fpr = (TileParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint) if tile else
            FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint))
@@ -328,7 +334,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"config[4]: tile-parallel single {size}x{size} frame, interleaved 8-row bands, " if tile else
                                     f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "
-                                   "max 16 steps/ray, 25 FPS pose stream, torso pass on",
+                                   "max 16 steps/ray, 25 FPS pose stream, torso pass on"
+                                   + (", regime A (opaque: sigma x40, rays terminate on T < 1e-4)" if args.regime == "A" else ""),
                        "grid": args.grid, "engine": engine, "frames_per_gpu": K,
                        "loop_iterations_enqueued": (getattr(getattr(scene.model, "_fused_state", None), "loop_hint", None)
                                                     or scene.opt.max_steps),

@@ -106,6 +106,11 @@ typedef struct {
     float *sigmas, *rgbs;                 /* [N] [N,3] */
     int32_t *state;                       /* [RN_HEAD_STATE_INTS] */
     uint32_t *block_counts;               /* [3 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums x 2 */
+    int32_t *live_slots;                  /* [N] or NULL.  Scratch for the list of live sample slots of an iteration: the
+                                             marchers write it and the network kernel then runs over st[6] live samples
+                                             instead of all n_alive * n_step slots (rays that end in the middle of their
+                                             n_step samples leave dead slots: 16 % of the benchmark stream).  NULL: the
+                                             network visits every slot and skips the dead ones.  Same pixels either way. */
     uint32_t order_w;                     /* 0: alive list starts in ray order.  Image width W (rays are row-major pixels,
                                              W % 8 == 0, N % W == 0, (N / W) % 8 == 0; otherwise treated as 0): the list
                                              starts in 8 x 8 pixel blocks, so neighbouring samples share more grid rows.

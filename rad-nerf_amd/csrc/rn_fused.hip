@@ -224,7 +224,7 @@ __device__ __forceinline__ void valu_out(const Acc32 &in, const float *wl, int h
 #ifdef RN_PHASE_CLOCK
 #define RN_PHASE_MARK(i) const uint64_t phase_t##i = wall_clock64()
 #define RN_PHASE_STORE()                                                                                        \
-    if (p.ambient && lane < 2 && sample + 1 < M) {                                                              \
+    if (p.ambient && lane < 2 && entry + 1 < M) {                                                               \
         p.ambient[2 * (size_t)sample] = (float)(lane ? phase_t3 - phase_t2 : phase_t1 - phase_t0);                \
         p.ambient[2 * (size_t)sample + 1] = (float)(lane ? phase_t4 - phase_t3 : phase_t2 - phase_t1);            \
     }
@@ -266,9 +266,14 @@ __global__ void __launch_bounds__(kF32Threads, kF32Waves / 4) k_nerf_fused(Fused
 
     const TileSchedule sched(n_tiles, kF32Waves, (uint32_t)wave);
     for (uint32_t tile = sched.first; tile < sched.end; tile += sched.stride) {
-        const uint32_t sample = tile * 32 + j;  // both lane halves work on the same 32 samples
-        bool live = sample < M;
-        if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;
+        const uint32_t entry = tile * 32 + j;  // both lane halves work on the same 32 samples
+        bool live = entry < M;
+        uint32_t sample = entry;  // the slot this lane's sample lives in
+        if (p.slots) {
+            if (live) sample = (uint32_t)p.slots[entry];
+        } else if (live && p.deltas) {
+            live = p.deltas[2 * (size_t)sample] != 0.0f;
+        }
         if (__ballot(live) == 0ull) continue;  // whole tile dead (wave-uniform)
 
         // ---- xyz grid (gridencoder/grid.py:145-161: (x + bound) / (2 bound)).  Round r: lane half h gathers level
@@ -414,6 +419,8 @@ __global__ void __launch_bounds__(kF32Threads, kF32Waves / 4) k_nerf_fused(Fused
 //
 // state words (int32), two banks of 8 selected by (iteration & 1):
 //   [0] n_alive  [1] step  [2] n_step  [3] M = n_alive * n_step  [4] active  [5] live-partial workgroups (0: default)
+//   [6] live samples listed by the marchers of this iteration (entries of rn_head_t.live_slots); zeroed by the previous
+//       iteration's compositor (by rn_head_begin for iteration 0), never by next_state()
 // plus stats at [16..]: iterations that did work, live samples, sample slots.
 constexpr int kLoopBlock = 256;
 
@@ -434,6 +441,36 @@ __device__ __forceinline__ void next_state(int32_t *st, uint32_t N, uint32_t n_a
     st[5] = 0;  // workgroups that hold live-sample partial sums of the coming iteration; 0 = ceil(n_alive / 256)
 }
 
+// The marchers' epilogue: every lane holds `emitted` live samples in slots base .. base + emitted - 1.  One atomicAdd per
+// workgroup reserves a run of the iteration's live list (its order is arrival order -- irrelevant, every sample is
+// independent), a block-wide scan places each lane's entries.  Returns the workgroup's live-sample count.
+__device__ __forceinline__ uint32_t list_live_slots(uint32_t emitted, uint32_t base, int32_t *live_count,
+                                                    int32_t *__restrict__ live_slots, uint32_t *sh /* [kLoopBlock / kWave + 1] */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = emitted;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();  // sh may still be read by the caller's previous phase
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kLoopBlock / kWave; w++) {
+        total += sh[w];
+        before += w < wave ? sh[w] : 0u;
+    }
+    if (live_slots) {
+        if (threadIdx.x == 0) sh[kLoopBlock / kWave] = total ? (uint32_t)atomicAdd(live_count, (int32_t)total) : 0u;
+        __syncthreads();
+        const uint32_t at = sh[kLoopBlock / kWave] + before + incl - emitted;
+        for (uint32_t k = 0; k < emitted; k++) live_slots[at + k] = (int32_t)(base + k);
+    }
+    return total;
+}
+
 // near/far (raymarching.cu:91-145) + loop initialisation (renderer.py:229-237)
 __global__ void __launch_bounds__(kLoopBlock)
 k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
@@ -444,6 +481,7 @@ k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     if (n == 0) {
         next_state(state, N, N, 0, max_steps);
+        state[6] = 0;
         for (int i = 8; i < 16; i++) state[i] = 0;  // statistics words [16..] accumulate across frames (caller-owned)
     }
     if (n >= N) return;
@@ -491,31 +529,25 @@ k_head_march(const int32_t *__restrict__ st, const int32_t *__restrict__ rays_al
              const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, float dt_gamma,
              uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
              const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ stats,
-             uint32_t *__restrict__ block_live) {
+             uint32_t *__restrict__ block_live, int32_t *__restrict__ live_count, int32_t *__restrict__ live_slots) {
     if (!st[4]) return;
     const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     uint32_t emitted = 0;
+    const uint32_t base = n * n_step;
     if (n < n_alive) {
         const int index = rays_alive[n];
         Dda s;
         s.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
         float t = rays_t[index];  // perturb is off at inference: no noise term (renderer.py:251)
-        const size_t base = (size_t)n * n_step;
-        emitted = s.walk<true>(t, n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
-        for (uint32_t k = emitted; k < n_step; k++) { deltas[(base + k) * 2] = 0.0f; deltas[(base + k) * 2 + 1] = 0.0f; }
+        emitted = s.walk<true>(t, n_step, xyzs + (size_t)base * 3, dirs + (size_t)base * 3, deltas + (size_t)base * 2);
+        for (uint32_t k = emitted; k < n_step; k++) { deltas[((size_t)base + k) * 2] = 0.0f; deltas[((size_t)base + k) * 2 + 1] = 0.0f; }
     }
-    // stats: live samples of this iteration.  One partial sum per workgroup, added up by the compaction kernel: a
-    // same-address atomic per wavefront (~1 300 per launch) serialised behind the L2s and cost 38 us per frame.
-    __shared__ uint32_t live_w[kLoopBlock / kWave];
-    for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off, 64);
-    if ((threadIdx.x & 63) == 0) live_w[threadIdx.x >> 6] = emitted;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t sum = 0;
-        for (int w = 0; w < kLoopBlock / kWave; w++) sum += live_w[w];
-        block_live[blockIdx.x] = sum;
-    }
+    // live samples of this iteration: listed for the network kernel, and counted -- one partial sum per workgroup, added up by
+    // the compaction kernel (a same-address atomic per wavefront for the statistic cost 38 us per frame)
+    __shared__ uint32_t sh[kLoopBlock / kWave + 1];
+    const uint32_t total = list_live_slots(emitted, base, live_count, live_slots, sh);
+    if (threadIdx.x == 0) block_live[blockIdx.x] = total;
     if (n == 0) { atomicAdd(&stats[RN_HEAD_ST_ITERS], 1); atomicAdd(&stats[RN_HEAD_ST_SLOTS], (int32_t)(n_alive * n_step)); }
 }
 
@@ -524,9 +556,10 @@ __global__ void __launch_bounds__(kLoopBlock)
 k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__restrict__ rays_alive,
                  float *__restrict__ rays_t, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                  const float *__restrict__ deltas, float *__restrict__ weights_sum, float *__restrict__ depth,
-                 float *__restrict__ image, uint32_t *__restrict__ block_counts) {
+                 float *__restrict__ image, uint32_t *__restrict__ block_counts, int32_t *__restrict__ st_next) {
     __shared__ uint32_t wave_cnt[kLoopBlock / kWave];
     if (!st[4]) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st_next[6] = 0;  // the marchers of the next iteration count their live samples here
     const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
     const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
     if (blockIdx.x * kLoopBlock >= n_alive) return;
@@ -583,6 +616,7 @@ struct MarchArgs {
     const uint8_t *grid;
     float *xyzs, *dirs, *deltas;
     uint32_t *block_live_next;
+    int32_t *live_slots;
 };
 
 template <bool MARCH>
@@ -651,24 +685,18 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
     if constexpr (MARCH) {
         if (!active_next) return;  // uniform
         uint32_t emitted = 0;
+        const uint32_t base = slot * n_step_next;
         if (keep) {
             Dda s;
             s.init(m.rays_o + (size_t)v * 3, m.rays_d + (size_t)v * 3, m.bound, m.dt_gamma, max_steps, m.cascade, m.grid_size, m.grid,
                    m.fars[v]);
             float t = m.rays_t[v];
-            const size_t base = (size_t)slot * n_step_next;
-            emitted = s.walk<true>(t, n_step_next, m.xyzs + base * 3, m.dirs + base * 3, m.deltas + base * 2);
-            for (uint32_t k = emitted; k < n_step_next; k++) { m.deltas[(base + k) * 2] = 0.0f; m.deltas[(base + k) * 2 + 1] = 0.0f; }
+            emitted = s.walk<true>(t, n_step_next, m.xyzs + (size_t)base * 3, m.dirs + (size_t)base * 3, m.deltas + (size_t)base * 2);
+            for (uint32_t k = emitted; k < n_step_next; k++) { m.deltas[((size_t)base + k) * 2] = 0.0f; m.deltas[((size_t)base + k) * 2 + 1] = 0.0f; }
         }
-        __syncthreads();  // red / wave_off are reused below
-        for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = emitted;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t sum = 0;
-            for (int w = 0; w < kLoopBlock / kWave; w++) sum += red[w];
-            m.block_live_next[blockIdx.x] = sum;
-        }
+        __shared__ uint32_t sh[kLoopBlock / kWave + 1];
+        const uint32_t total = list_live_slots(emitted, base, st_next + 6, m.live_slots, sh);
+        if (threadIdx.x == 0) m.block_live_next[blockIdx.x] = total;
     }
 }
 
@@ -1004,8 +1032,8 @@ static void launch_fused(const FusedParams &p, hipStream_t s) {
 
 static int run_fused(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
                      const rn_grid_t *gx, const rn_grid_t *gw, const float *packed, const float *bias, float bound,
-                     float *sigmas, float *rgbs, float *ambient, int mlp_dtype, hipStream_t s) {
-    FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient};
+                     float *sigmas, float *rgbs, float *ambient, int mlp_dtype, hipStream_t s, const int32_t *slots = nullptr) {
+    FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient, slots};
     const bool prof = prof_enabled();
     if (prof) prof_begin(s);
     if (mlp_dtype == RN_F32_SPLIT) {
@@ -1123,13 +1151,15 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
         if (it == first_iter)
             hipLaunchKernelGGL(k_head_march, rgrid, rblock, 0, s, st, alive, h->rays_t, h->rays_o, h->rays_d, h->bound,
                                h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
-                               h->deltas, h->state, block_live[it & 1u]);
-        run_fused(h->xyzs, h->dirs, h->deltas, h->N, st + 3, grid_xyz, grid_amb, packed, bias, h->bound, h->sigmas, h->rgbs,
-                  nullptr, mlp_dtype, s);
+                               h->deltas, h->state, block_live[it & 1u], st + 6, h->live_slots);
+        // the network runs over the iteration's live list when the caller gave room for one (st[6] entries), else over all
+        // st[3] slots, skipping the dead ones by their deltas
+        run_fused(h->xyzs, h->dirs, h->deltas, h->N, h->live_slots ? st + 6 : st + 3, grid_xyz, grid_amb, packed, bias, h->bound,
+                  h->sigmas, h->rgbs, nullptr, mlp_dtype, s, h->live_slots);
         hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
-                           h->deltas, h->weights_sum, h->depth, h->image, h->block_counts);
+                           h->deltas, h->weights_sum, h->depth, h->image, h->block_counts, st_next);
         const MarchArgs m{h->rays_t, h->rays_o, h->rays_d, h->fars, h->bound, h->dt_gamma, h->cascade, h->grid_size, h->bitfield,
-                          h->xyzs, h->dirs, h->deltas, block_live[(it + 1) & 1u]};
+                          h->xyzs, h->dirs, h->deltas, block_live[(it + 1) & 1u], h->live_slots};
         if (it + 1 < first_iter + n_iters)
             hipLaunchKernelGGL(k_head_compact<true>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
                                h->block_counts, block_live[it & 1u], h->state, m);

@@ -114,6 +114,11 @@ struct FusedParams {
     const float *packed, *bias;
     float bound;
     float *sigmas, *rgbs, *ambient;
+    // optional list of live sample slots: entry j names the slot (row of xyzs / dirs / sigmas / rgbs / ambient) that the j-th
+    // sample of the launch works on, every entry is live and M counts entries.  NULL: sample j is slot j (dead where
+    // deltas[2 j] == 0).  Inside the frame loop the marchers write it, so the network skips the dead slots of rays that
+    // ended in the middle of their n_step samples (16 % of the slots of the benchmark stream).
+    const int32_t *slots;
 };
 
 // XCD-aware tile schedule.  Workgroups are dealt round-robin over the 8 XCDs (workgroup b lands on XCD b % 8; used for

@@ -199,9 +199,14 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
 
     const TileSchedule sched(n_tiles, kWavesPerBlock, (uint32_t)wave);
     for (uint32_t tile = sched.first; tile < sched.end; tile += sched.stride) {
-        const uint32_t sample = tile * 64 + lane;
-        bool live = sample < M;
-        if (live && p.deltas) live = p.deltas[2 * (size_t)sample] != 0.0f;
+        const uint32_t entry = tile * 64 + lane;
+        bool live = entry < M;
+        uint32_t sample = entry;  // the slot this lane's sample lives in
+        if (p.slots) {
+            if (live) sample = (uint32_t)p.slots[entry];
+        } else if (live && p.deltas) {
+            live = p.deltas[2 * (size_t)sample] != 0.0f;
+        }
         if (__ballot(live) == 0ull) continue;  // whole tile dead (wave-uniform)
 
         // ---- xyz grid, one sample per lane -> 16 fp16 feature pairs in the staging tile

@@ -46,7 +46,7 @@ class HeadT(C.Structure):
                 ("grid_size", _u32), ("T_thresh", _f32), ("nears", _ptr), ("fars", _ptr), ("weights_sum", _ptr),
                 ("depth", _ptr), ("image", _ptr), ("rays_alive_a", _ptr), ("rays_alive_b", _ptr), ("rays_t", _ptr),
                 ("xyzs", _ptr), ("dirs", _ptr), ("deltas", _ptr), ("sigmas", _ptr), ("rgbs", _ptr), ("state", _ptr),
-                ("block_counts", _ptr), ("order_w", _u32)]
+                ("block_counts", _ptr), ("live_slots", _ptr), ("order_w", _u32)]
 
 
 RN_HEAD_STATE_INTS = 32
@@ -199,6 +199,7 @@ class FusedState:
         self.state = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32, device=d)
         self.stats_prev = [0, 0, 0]
         self.block_counts = torch.empty(3 * ((N + 255) // 256 + 1), dtype=i32, device=d)
+        self.live_slots = torch.empty(N, dtype=i32, device=d)   # live-sample list of the iteration in flight
         self._N = N
 
 
@@ -318,6 +319,7 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     h.deltas = st.samples.data_ptr() + N * 6 * 4
     h.sigmas, h.rgbs = st.sigmas.data_ptr(), st.rgbs.data_ptr()
     h.state, h.block_counts = st.state.data_ptr(), st.block_counts.data_ptr()
+    h.live_slots = st.live_slots.data_ptr() if getattr(model.opt, "live_list", True) else None
     # image width, if the caller said the rays are the row-major pixels of an image (SyntheticScene does): the loop then
     # walks the rays in 8 x 8 pixel blocks (more shared grid rows per wave; no pixel changes)
     h.order_w = int(getattr(model, "ray_order_width", 0) or 0)
