@@ -53,7 +53,10 @@ def parse():
                          "with the hint the device flags any frame it was too small for and the run is repeated without it")
     ap.add_argument("--regime", default="B", choices=["A", "B"],
                     help="SURVEY 8(d): B = worst case (sigma ~ 1, no ray terminates on opacity; default, headline), "
-                         "A = opaque (sigma scaled up x40: early termination active)")
+                         "A = opaque (sigma row x80 -> sigma ~ 20..300 inside the head: early termination active)")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="time the dominant kernel's launches (HIP events on its dispatches) on every n-th step of the timed region; "
+                         "a timed dispatch costs ~10 us of idle GPU, so timing all of them lowers the frame rate by 5 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -220,7 +223,7 @@ def main():
                            opt=default_opt(engine=engine, mlp_dtype=args.mlp, **GRIDS[args.grid]))
     if args.regime == "A":
         with torch.no_grad():
-            scene.model.sigma_net.net[-1].weight[0].abs_().mul_(40.0)
+            scene.model.sigma_net.net[-1].weight[0].abs_().mul_(80.0)
     tile = args.workload == "tile"
     fpr = (TileParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint) if tile else
            FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint))
@@ -238,7 +241,7 @@ def main():
         timer = hip.KernelTimer(kernel_select(engine, acc))
         hip.set_timer(timer)
         if engine == "fused":
-            hip.prof_enable(True)
+            hip.prof_enable(os.environ.get("RN_BENCH_PROF", "1") != "0")   # 0: tools/trace_gaps.py checks the timing costs nothing
             c0 = fpr.loop_counters() or [0, 0, 0]
         from radnerf.parallel import LoopHintTooSmall
         for attempt in range(2):
@@ -247,6 +250,8 @@ def main():
             short = 0
             try:
                 for s in range(W, W + K):
+                    if engine == "fused":
+                        hip.prof_pause((s - W) % max(args.time_every, 1) != 0)
                     fpr.step(s)
                 fpr.finish()
             except LoopHintTooSmall:        # the device flagged a frame: this timing is void, repeat with every iteration
@@ -288,23 +293,32 @@ def main():
         res = timer.results()
         roof = None
         if engine == "fused" and fused_launches:
-            nbytes = live_total * FUSED_BYTES_PER_SAMPLE
+            # the kernel was timed on every --time-every-th step; the stream's frames hold the same number of samples to within
+            # a fraction of a percent, so the timed steps' share of the counted samples is their share of the steps
+            timed_steps = len(range(0, K, max(args.time_every, 1)))
+            timed_frac = timed_steps / K
+            live_timed = live_total * timed_frac
+            iters_timed = int(round(iters_total * timed_frac))
+            nbytes = live_timed * FUSED_BYTES_PER_SAMPLE
             achieved = nbytes / (fused_ms * 1e-3) / 1e9
-            tflops = live_total * MLP_FLOP_PER_SAMPLE / (fused_ms * 1e-3) / 1e12
+            tflops = live_timed * MLP_FLOP_PER_SAMPLE / (fused_ms * 1e-3) / 1e12
             # The kernel does both of the path's heavy jobs (grid gathers and the MLP contraction).  With fp32 MFMA the
             # matrix-core roof is the closer (binding) one; on the 16-bit matrix cores the contraction is ~16x cheaper and
             # the gathers bind.  `bound` names the binding roof, the other view rides along.
             tkey = {"f32": "nerf_fused", "f16": "nerf_fused_h16", "f32x2": "nerf_fused_x2"}[args.mlp]
             common = dict(traffic=fpr.measured_traffic(tkey),
                           launches=fused_launches, avg_launch_ms=fused_ms / fused_launches,
-                          share_of_step=fused_ms / (elapsed * 1e3), launches_with_work=iters_total,
-                          avg_launch_ms_with_work=sum(fused_durs[:iters_total]) / max(iters_total, 1),
-                          note="launches/avg_launch_ms count every launch of the kernel (max_steps per frame, as rocprof "
+                          share_of_step=fused_ms / (elapsed * 1e3 * timed_frac), launches_with_work=iters_timed,
+                          avg_launch_ms_with_work=sum(fused_durs[:iters_timed]) / max(iters_timed, 1),
+                          timed_steps=timed_steps,
+                          note="HIP events on the kernel's dispatches, on every --time-every-th step of the timed region "
+                               "(a timed dispatch costs ~10 us of idle GPU; timing all of them lowers the frame rate by 5 %); "
+                               "launches/avg_launch_ms count every timed launch of the kernel (as rocprof "
                                "does); iterations past the end of the loop launch with zero samples and exit at once; "
                                "traffic = HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes in profiles/")
             mfma_peak = MFMA_F32_PEAK_TFLOPS if args.mlp == "f32" else MFMA_F16_PEAK_TFLOPS
             mfma_view = dict(achieved=tflops, peak=mfma_peak, unit="TFLOP/s", frac=tflops / mfma_peak,
-                             algorithmic_flop_per_launch=live_total * MLP_FLOP_PER_SAMPLE / fused_launches,
+                             algorithmic_flop_per_launch=live_timed * MLP_FLOP_PER_SAMPLE / fused_launches,
                              algorithmic_flop_per_sample=MLP_FLOP_PER_SAMPLE)
             hbm_view = dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                             algorithmic_bytes_per_launch=nbytes / fused_launches,
@@ -335,7 +349,7 @@ def main():
             "config": {"workload": (f"config[4]: tile-parallel single {size}x{size} frame, interleaved 8-row bands, " if tile else
                                     f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "
                                    "max 16 steps/ray, 25 FPS pose stream, torso pass on"
-                                   + (", regime A (opaque: sigma x40, rays terminate on T < 1e-4)" if args.regime == "A" else ""),
+                                   + (", regime A (opaque: sigma ~ 20..300 inside the head, rays terminate on T < 1e-4)" if args.regime == "A" else ""),
                        "grid": args.grid, "engine": engine, "frames_per_gpu": K,
                        "loop_iterations_enqueued": (getattr(getattr(scene.model, "_fused_state", None), "loop_hint", None)
                                                     or scene.opt.max_steps),
@@ -345,7 +359,7 @@ def main():
             "sample_slots_per_frame": slots_pf * (world if tile else 1),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.regime == "B":
             cb_size = args.cpu_baseline_size or size
             out["cpu_baseline"] = cpu_baseline({}, cb_size, GRIDS[args.grid])
         print(json.dumps(out))

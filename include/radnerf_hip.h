@@ -61,6 +61,9 @@ int rn_device_count(void);
 /* HIP-event timing of the fused per-sample kernel on its launch stream: enable(1) resets the record,
  * collect() waits for the recorded events and returns the number of launches and their summed duration. */
 int rn_prof_enable(int on);
+/* Suspend (1) / resume (0) the timing without resetting the record: a timed dispatch carries two barrier packets
+ * (~10 us of idle GPU around it), so a caller that also measures whole-job throughput times a sample of its steps. */
+int rn_prof_pause(int paused);
 int rn_prof_collect(uint32_t *launches, float *total_ms);
 /* Per-launch durations (ms) in launch order; returns how many were written (<= capacity) or a negative error. */
 int rn_prof_durations(float *out_ms, uint32_t capacity);

@@ -7,6 +7,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
@@ -20,8 +21,14 @@ void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 // HIP-event timing of the dominant kernel (rn_prof_enable / rn_prof_collect)
 bool prof_enabled();
-void prof_begin(hipStream_t s);
-void prof_end(hipStream_t s);
+void prof_pair(hipEvent_t *start, hipEvent_t *stop);
+// launch with the timing events of prof_pair() attached to the dispatch (plain launch when timing is off)
+#define RN_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                      \
+    do {                                                                                       \
+        hipEvent_t rn_e0_, rn_e1_;                                                             \
+        ::rn::prof_pair(&rn_e0_, &rn_e1_);                                                     \
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, rn_e0_, rn_e1_, 0, __VA_ARGS__); \
+    } while (0)
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(rn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1027,15 +1027,13 @@ static void launch_fused(const FusedParams &p, hipStream_t s) {
     uint32_t blocks = div_up(n_tiles, kF32Waves);
     const uint32_t cap = (uint32_t)num_cus();  // one persistent workgroup per CU (96.5 KB of LDS each)
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_nerf_fused<TX, TW>), dim3(blocks), dim3(kF32Threads), 0, s, p);
+    RN_LAUNCH_TIMED((k_nerf_fused<TX, TW>), dim3(blocks), dim3(kF32Threads), s, p);
 }
 
 static int run_fused(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
                      const rn_grid_t *gx, const rn_grid_t *gw, const float *packed, const float *bias, float bound,
                      float *sigmas, float *rgbs, float *ambient, int mlp_dtype, hipStream_t s, const int32_t *slots = nullptr) {
     FusedParams p{xyzs, dirs, deltas, M, m_dev, grid_args(gx), grid_args(gw), packed, bias, bound, sigmas, rgbs, ambient, slots};
-    const bool prof = prof_enabled();
-    if (prof) prof_begin(s);
     if (mlp_dtype == RN_F32_SPLIT) {
         launch_fused_x2(p, gx->dtype, gw->dtype, (uint32_t)num_cus(), s);
     } else if (mlp_dtype == RN_F16) {
@@ -1046,7 +1044,6 @@ static int run_fused(const float *xyzs, const float *dirs, const float *deltas, 
     else if (gx->dtype == RN_F16 && gw->dtype == RN_F16) launch_fused<__half, __half>(p, s);
     else if (gx->dtype == RN_F32) launch_fused<float, __half>(p, s);
     else launch_fused<__half, float>(p, s);
-    if (prof) prof_end(s);
     return RN_OK;
 }
 

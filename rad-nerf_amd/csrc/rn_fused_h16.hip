@@ -358,10 +358,10 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
 
 void launch_fused_h16(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t blocks, hipStream_t s) {
     const dim3 g(blocks), b(kFusedThreads);
-    if (gx_dtype == RN_F32 && gw_dtype == RN_F32) hipLaunchKernelGGL((k_nerf_fused_h16<float, float>), g, b, 0, s, p);
-    else if (gx_dtype == RN_F16 && gw_dtype == RN_F16) hipLaunchKernelGGL((k_nerf_fused_h16<__half, __half>), g, b, 0, s, p);
-    else if (gx_dtype == RN_F32) hipLaunchKernelGGL((k_nerf_fused_h16<float, __half>), g, b, 0, s, p);
-    else hipLaunchKernelGGL((k_nerf_fused_h16<__half, float>), g, b, 0, s, p);
+    if (gx_dtype == RN_F32 && gw_dtype == RN_F32) RN_LAUNCH_TIMED((k_nerf_fused_h16<float, float>), g, b, s, p);
+    else if (gx_dtype == RN_F16 && gw_dtype == RN_F16) RN_LAUNCH_TIMED((k_nerf_fused_h16<__half, __half>), g, b, s, p);
+    else if (gx_dtype == RN_F32) RN_LAUNCH_TIMED((k_nerf_fused_h16<float, __half>), g, b, s, p);
+    else RN_LAUNCH_TIMED((k_nerf_fused_h16<__half, float>), g, b, s, p);
 }
 
 void launch_pack_nerf_h16(const RawW &w, float *packed, hipStream_t s) {

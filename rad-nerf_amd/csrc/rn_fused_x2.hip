@@ -404,10 +404,10 @@ void launch_fused_x2(const FusedParams &p, int gx_dtype, int gw_dtype, uint32_t 
     uint32_t blocks = div_up((p.M + 63u) >> 6, kX2Waves);
     if (blocks > n_cus) blocks = n_cus;
     const dim3 g(blocks), b(kX2Threads);
-    if (gx_dtype == RN_F32 && gw_dtype == RN_F32) hipLaunchKernelGGL((k_nerf_fused_x2<float, float>), g, b, 0, s, p);
-    else if (gx_dtype == RN_F16 && gw_dtype == RN_F16) hipLaunchKernelGGL((k_nerf_fused_x2<__half, __half>), g, b, 0, s, p);
-    else if (gx_dtype == RN_F32) hipLaunchKernelGGL((k_nerf_fused_x2<float, __half>), g, b, 0, s, p);
-    else hipLaunchKernelGGL((k_nerf_fused_x2<__half, float>), g, b, 0, s, p);
+    if (gx_dtype == RN_F32 && gw_dtype == RN_F32) RN_LAUNCH_TIMED((k_nerf_fused_x2<float, float>), g, b, s, p);
+    else if (gx_dtype == RN_F16 && gw_dtype == RN_F16) RN_LAUNCH_TIMED((k_nerf_fused_x2<__half, __half>), g, b, s, p);
+    else if (gx_dtype == RN_F32) RN_LAUNCH_TIMED((k_nerf_fused_x2<float, __half>), g, b, s, p);
+    else RN_LAUNCH_TIMED((k_nerf_fused_x2<__half, float>), g, b, s, p);
 }
 
 void launch_pack_nerf_x2(const RawW &w, float *packed, hipStream_t s) {

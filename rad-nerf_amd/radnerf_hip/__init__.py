@@ -72,6 +72,8 @@ _lib.rn_compact_rays_workspace.argtypes = [_u32]
 
 _lib.rn_prof_enable.argtypes = [C.c_int]
 _lib.rn_prof_enable.restype = C.c_int
+_lib.rn_prof_pause.argtypes = [C.c_int]
+_lib.rn_prof_pause.restype = C.c_int
 _lib.rn_prof_collect.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
 _lib.rn_prof_collect.restype = C.c_int
 
@@ -82,12 +84,17 @@ _lib.rn_prof_durations.restype = C.c_int
 
 def exported_symbols():
     """Every symbol include/radnerf_hip.h declares (used by the CPU-side load test)."""
-    return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count", "rn_prof_enable",
+    return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count", "rn_prof_enable", "rn_prof_pause",
                                        "rn_prof_collect", "rn_prof_durations", "rn_march_rays_train_workspace", "rn_compact_rays_workspace"])
 
 
 def prof_enable(on=True):
     _lib.rn_prof_enable(1 if on else 0)
+
+
+def prof_pause(paused=True):
+    """Suspend / resume the kernel timing without dropping what was recorded."""
+    _lib.rn_prof_pause(1 if paused else 0)
 
 
 def prof_collect():
