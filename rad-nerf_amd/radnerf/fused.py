@@ -233,6 +233,37 @@ class LoopStats(dict):
         self._load()
         return super().__contains__(k)
 
+    # iteration / copying / comparison / printing also see the loaded numbers (dict(stats) would otherwise copy nothing)
+    def __iter__(self):
+        self._load()
+        return super().__iter__()
+
+    def keys(self):
+        self._load()
+        return super().keys()
+
+    def items(self):
+        self._load()
+        return super().items()
+
+    def values(self):
+        self._load()
+        return super().values()
+
+    def __len__(self):
+        self._load()
+        return super().__len__()
+
+    def __eq__(self, other):
+        self._load()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._load()
+        return super().__repr__()
+
 
 def loop_counters(model):
     """Cumulative device-side loop counters (iterations, live samples, sample slots); synchronises."""

@@ -405,3 +405,20 @@ def test_fused_network_with_non_power_of_two_levels(po, hiplib, grid, mlp):
     np.testing.assert_allclose(amb.cpu().numpy(), ea, rtol=0, atol=2e-5)
     np.testing.assert_allclose(sigma.cpu().numpy(), es, rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(color.cpu().numpy(), ec, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f32x2", "f16"])
+def test_live_sample_list_changes_no_pixel(hiplib, mlp):
+    """rn_head_t.live_slots (the marchers list the live sample slots, the network kernels skip the dead ones) against the
+    plain walk over all n_alive * n_step slots (opt.live_list = False): same image, depth and loop statistics, bit for bit."""
+    outs = []
+    for live_list in (True, False):
+        scene = _scene(96, "fused", mlp_dtype=mlp, live_list=live_list)
+        with torch.no_grad():
+            for i in range(2):
+                out = scene.render(i)
+        outs.append((out["image"].clone(), out["depth"].clone(), dict(scene.model.last_stats)))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(torch.nan_to_num(outs[0][1], nan=-1.0), torch.nan_to_num(outs[1][1], nan=-1.0))
+    assert outs[0][2] == outs[1][2]
+    assert outs[0][2]["live_samples"] < outs[0][2]["sample_slots"]      # there ARE dead slots to skip
