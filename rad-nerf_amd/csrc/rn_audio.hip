@@ -25,10 +25,16 @@ struct AudioW {
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : 0.02f * v; }  // nn.LeakyReLU(0.02)
 
-__device__ __forceinline__ void stage(float *dst, const float *__restrict__ src, int n) {
-    __syncthreads();  // previous users of dst are done
-    for (int i = threadIdx.x; i < n; i += kAudioThreads) dst[i] = src[i];
-    __syncthreads();
+// How many lanes share one output (a power of two <= 16): layers with few outputs would otherwise leave most of the
+// workgroup idle behind a few long dot products.  The partial sums meet in a __shfl_xor tree.
+__device__ __forceinline__ int split_for(int total) {
+    int split = 1;
+    while (split < 16 && total * split * 2 <= kAudioThreads) split *= 2;
+    return split;
+}
+__device__ __forceinline__ float quad_sum(float v, int split) {
+    for (int d = 1; d < split; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
 }
 
 // Conv1d(kernel 3, padding 1) + LeakyReLU over `frames` independent [cin, len_in] maps held in LDS.
@@ -37,33 +43,68 @@ __device__ __forceinline__ void conv3(const float *in, float *out, const float *
                                       int cin, int cout, int len_in, int stride) {
     const int len_out = (len_in - 1) / stride + 1;
     const int total = frames * cout * len_out;
-    for (int o = threadIdx.x; o < total; o += kAudioThreads) {
-        const int pos = o % len_out, co = (o / len_out) % cout, f = o / (len_out * cout);
-        const float *x = in + (size_t)f * cin * len_in;
-        const float *wr = w + (size_t)co * cin * 3;
-        const int c0 = pos * stride - 1;
-        float acc = bias[co];
-        for (int ci = 0; ci < cin; ci++) {
+    const int split = split_for(total);
+    for (int base = 0; base < total * split; base += kAudioThreads) {   // uniform trip count: the shuffles need whole waves
+        const int id = base + (int)threadIdx.x, o = id / split, part = id % split;
+        float acc = 0.0f;
+        if (o < total) {
+            const int pos = o % len_out, co = (o / len_out) % cout, f = o / (len_out * cout);
+            const float *x = in + (size_t)f * cin * len_in;
+            const float *wr = w + (size_t)co * cin * 3;
+            const int c0 = pos * stride - 1;
+            for (int ci = part; ci < cin; ci += split) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int p = c0 + k;
-                if (p >= 0 && p < len_in) acc += wr[ci * 3 + k] * x[ci * len_in + p];
+                for (int k = 0; k < 3; k++) {
+                    const int p = c0 + k;
+                    if (p >= 0 && p < len_in) acc += wr[ci * 3 + k] * x[ci * len_in + p];
+                }
             }
         }
-        out[o] = leaky(acc);
+        acc = quad_sum(acc, split);
+        if (o < total && part == 0) out[o] = leaky(acc + bias[(o / len_out) % cout]);
     }
 }
 
 // rows: y[f][o] = act(b[o] + sum_k W[o][k] x[f][k]); w [dout][din] in LDS
 __device__ __forceinline__ void linear(const float *in, float *out, const float *w, const float *__restrict__ bias, int frames,
                                        int din, int dout, bool act) {
-    for (int o = threadIdx.x; o < frames * dout; o += kAudioThreads) {
-        const int f = o / dout, r = o % dout;
-        float acc = bias[r];
-        for (int k = 0; k < din; k++) acc += w[r * din + k] * in[f * din + k];
-        out[o] = act ? leaky(acc) : acc;
+    const int total = frames * dout;
+    const int split = split_for(total);
+    for (int base = 0; base < total * split; base += kAudioThreads) {
+        const int id = base + (int)threadIdx.x, o = id / split, part = id % split;
+        float acc = 0.0f;
+        if (o < total) {
+            const int f = o / dout, r = o % dout;
+            for (int k = part; k < din; k += split) acc += w[r * din + k] * in[f * din + k];
+        }
+        acc = quad_sum(acc, split);
+        if (o < total && part == 0) {
+            acc += bias[o % dout];
+            out[o] = act ? leaky(acc) : acc;
+        }
     }
 }
+
+// The next layer's weights travel global -> registers while the current layer computes, then registers -> the other LDS
+// buffer: the workgroup waits for one memory round trip per kernel instead of one per layer.
+constexpr int kPrefetch = kMaxWeights / kAudioThreads;  // 48 floats per lane
+struct Prefetch {
+    float v[kPrefetch];
+    __device__ __forceinline__ void load(const float *__restrict__ src, int n) {
+#pragma unroll
+        for (int i = 0; i < kPrefetch; i++) {
+            const int at = i * kAudioThreads + (int)threadIdx.x;
+            v[i] = at < n ? src[at] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void store(float *dst, int n) const {  // caller syncs before (dst free) and after (dst ready)
+#pragma unroll
+        for (int i = 0; i < kPrefetch; i++) {
+            const int at = i * kAudioThreads + (int)threadIdx.x;
+            if (at < n) dst[at] = v[i];
+        }
+    }
+};
 
 // window source: explicit windows [n][frames][dim_in][16], or cut from a stream [T][dim_in][16] (nerf/utils.py:56-72)
 struct Source {
@@ -74,12 +115,14 @@ struct Source {
 
 // AudioNet on ONE frame per workgroup: blockIdx.x = window * frames_per_window + t; codes [n * frames][dim_aud]
 __global__ void __launch_bounds__(kAudioThreads) k_audio_frames(AudioW w, Source src, float *__restrict__ codes) {
-    __shared__ float wts[kMaxWeights];
+    __shared__ float wts0[kMaxWeights], wts1[kMaxWeights];  // weights of the layer computing / of the next one
     __shared__ float bufA[kMaxDimIn * kWin];  // ping
     __shared__ float bufB[32 * 8];            // pong (largest: conv1 output)
     const int frames = w.has_att ? kSeq : 1;
     const int cin0 = (int)w.dim_in, A = (int)w.dim_aud;
     const uint32_t win = blockIdx.x / frames, t = blockIdx.x % frames;
+    Prefetch pre;
+    pre.load(w.conv_w[0], 32 * cin0 * 3);
 
     // the frame's input map: x[:, :, 8 - 8 : 8 + 8] of nerf/network.py:62-63 is the whole 16-sample frame
     for (int i = threadIdx.x; i < cin0 * kWin; i += kAudioThreads) {
@@ -93,38 +136,55 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_frames(AudioW w, Source
         }
         bufA[i] = v;
     }
-    // AudioNet.encoder_conv: dim_in -> 32 -> 32 -> 64 -> 64, lengths 16 -> 8 -> 4 -> 2 -> 1
-    stage(wts, w.conv_w[0], 32 * cin0 * 3);
-    conv3(bufA, bufB, wts, w.conv_b[0], 1, cin0, 32, 16, 2);
-    stage(wts, w.conv_w[1], 32 * 32 * 3);
-    conv3(bufB, bufA, wts, w.conv_b[1], 1, 32, 32, 8, 2);
-    stage(wts, w.conv_w[2], 64 * 32 * 3);
-    conv3(bufA, bufB, wts, w.conv_b[2], 1, 32, 64, 4, 2);
-    stage(wts, w.conv_w[3], 64 * 64 * 3);
-    conv3(bufB, bufA, wts, w.conv_b[3], 1, 64, 64, 2, 2);  // -> [64][1]
-    // encoder_fc1: Linear(64, 64) + LeakyReLU, Linear(64, dim_aud)
-    stage(wts, w.fc_w[0], 64 * 64);
-    linear(bufA, bufB, wts, w.fc_b[0], 1, 64, 64, true);
-    stage(wts, w.fc_w[1], A * 64);
-    linear(bufB, codes + (size_t)blockIdx.x * A, wts, w.fc_b[1], 1, 64, A, false);
+    pre.store(wts0, 32 * cin0 * 3);
+    __syncthreads();
+    // AudioNet.encoder_conv: dim_in -> 32 -> 32 -> 64 -> 64, lengths 16 -> 8 -> 4 -> 2 -> 1; then encoder_fc1:
+    // Linear(64, 64) + LeakyReLU, Linear(64, dim_aud).  Layer l computes from wts[l & 1] while layer l + 1's weights load.
+    pre.load(w.conv_w[1], 32 * 32 * 3);
+    conv3(bufA, bufB, wts0, w.conv_b[0], 1, cin0, 32, 16, 2);
+    pre.store(wts1, 32 * 32 * 3);
+    __syncthreads();
+    pre.load(w.conv_w[2], 64 * 32 * 3);
+    conv3(bufB, bufA, wts1, w.conv_b[1], 1, 32, 32, 8, 2);
+    pre.store(wts0, 64 * 32 * 3);
+    __syncthreads();
+    pre.load(w.conv_w[3], 64 * 64 * 3);
+    conv3(bufA, bufB, wts0, w.conv_b[2], 1, 32, 64, 4, 2);
+    pre.store(wts1, 64 * 64 * 3);
+    __syncthreads();
+    pre.load(w.fc_w[0], 64 * 64);
+    conv3(bufB, bufA, wts1, w.conv_b[3], 1, 64, 64, 2, 2);  // -> [64][1]
+    pre.store(wts0, 64 * 64);
+    __syncthreads();
+    pre.load(w.fc_w[1], A * 64);
+    linear(bufA, bufB, wts0, w.fc_b[0], 1, 64, 64, true);
+    pre.store(wts1, A * 64);
+    __syncthreads();
+    linear(bufB, codes + (size_t)blockIdx.x * A, wts1, w.fc_b[1], 1, 64, A, false);
 }
 
 // AudioAttNet on one window per workgroup: codes [n][8][A] -> enc [n][A]
 __global__ void __launch_bounds__(kAudioThreads) k_audio_attend(AudioW w, const float *__restrict__ codes_all,
                                                                 float *__restrict__ enc) {
-    __shared__ float wts[64 * 16 * 3];
+    __shared__ float wts[64 * 16 * 3 + 16 * 8 * 3 + 8 * 4 * 3 + 4 * 2 * 3 + 2 * 1 * 3];  // all five conv layers
     __shared__ float bufA[64 * kSeq], bufB[16 * kSeq], codes[kSeq * 64], att[kSeq];
     const int A = (int)w.dim_aud;
     const uint32_t win = blockIdx.x;
+    const int chans[6] = {A, 16, 8, 4, 2, 1};
+    int woff[6];
+    woff[0] = 0;
+    for (int l = 0; l < 5; l++) woff[l + 1] = woff[l] + chans[l + 1] * chans[l] * 3;
+    for (int l = 0; l < 5; l++)   // one round trip for all weights (3.6 k floats) instead of one per layer
+        for (int i = threadIdx.x; i < woff[l + 1] - woff[l]; i += kAudioThreads) wts[woff[l] + i] = w.att_conv_w[l][i];
     for (int i = threadIdx.x; i < kSeq * A; i += kAudioThreads) codes[i] = codes_all[(size_t)win * kSeq * A + i];
     __syncthreads();
     // x [8, A] -> permute -> [A channels][8 positions]
     for (int i = threadIdx.x; i < A * kSeq; i += kAudioThreads) bufA[i] = codes[(i % kSeq) * A + i / kSeq];
-    const int chans[6] = {A, 16, 8, 4, 2, 1};
+    __syncthreads();
     float *a = bufA, *b = bufB;
     for (int l = 0; l < 5; l++) {
-        stage(wts, w.att_conv_w[l], chans[l + 1] * chans[l] * 3);
-        conv3(a, b, wts, w.att_conv_b[l], 1, chans[l], chans[l + 1], kSeq, 1);
+        conv3(a, b, wts + woff[l], w.att_conv_b[l], 1, chans[l], chans[l + 1], kSeq, 1);
+        __syncthreads();
         float *t = a; a = b; b = t;
     }
     __syncthreads();  // a: [1][8] scores
