@@ -3,17 +3,18 @@
 // C ABI: include/radnerf_fused.h.  What is computed: nerf/network.py:222-283 per sample and the inference
 // branch of nerf/renderer.py:225-262 per frame.  How (MI355X-first):
 //
-//  * one wavefront owns a tile of 64 samples.  Gather phases run one sample per lane (multires grid rows
-//    fetched with 8-byte loads, same device code as the standalone encoder, so features are bit-identical);
-//    MLP phases run on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains): outputs on the
-//    32 rows of the tile, samples on its 32 columns, two column tiles (= 64 samples) per wave so every
-//    weight fragment read from LDS feeds two MFMAs.
-//  * lane l of an MFMA supplies B[k = l>>5][col = l&31]; one v_permlane32_swap per feature pair turns the
-//    "one sample per lane" registers into the B operands of both column tiles.  A 32x32 accumulator has the
-//    sample on the lane and the output row on the register index, i.e. it already IS the B operand of the
-//    next layer (k order permuted -- the weight image is packed in that order once, on the device).
-//  * all weights (95.7 KB fp32) sit in LDS for the lifetime of a persistent 512-thread workgroup (one per
-//    CU, two waves per SIMD so one wave's gathers overlap the other's MFMAs).
+//  * one wavefront owns a tile of 32 samples; both lane halves work on the same samples.  A gather round has lane half
+//    h fetch level 2 r + h of its sample (multires grid rows with 8-byte loads, same device code as the standalone
+//    encoder, so features are bit-identical); the MLP phases run on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains):
+//    outputs on the 32 rows of the tile, samples on its 32 columns, k on the lane half -- so a gathered feature IS the
+//    B operand of an MFMA step (no cross-lane move) and a grid costs 8 rounds, not 16 levels, of latency.
+//  * a 32x32 accumulator has the sample on the lane and the output row on the register index, i.e. it already IS the
+//    B operand of the next layer (k order permuted -- the weight image is packed in that order once, on the device).
+//  * all weights (95.7 KB fp32) sit in LDS for the lifetime of a persistent 512-thread workgroup (one per CU, two
+//    waves per SIMD).  fp32 MFMA and fp32 VALU work share the FMA rate of a SIMD ("where the time goes"),
+//    so the instruction stream around the MFMAs is kept short: per-level plans (rn_grid_dev.h), one-instruction ReLU.
+//  * the torso pass (k_torso_fused) keeps the older 64-sample form: two column tiles per wave, one
+//    v_permlane32_swap per feature pair to build both B operands.
 //  * inputs that are the same for every sample of a frame (audio code, eye, individual code) never enter
 //    the per-sample GEMMs: they are folded into 3 x 64 bias values per frame, used as the accumulators'
 //    initial value.  Outputs narrower than a tile (ambient 2, sigma 1, rgb 3) are VALU dot products over
