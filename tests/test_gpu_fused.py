@@ -422,3 +422,18 @@ def test_live_sample_list_changes_no_pixel(hiplib, mlp):
     assert torch.equal(torch.nan_to_num(outs[0][1], nan=-1.0), torch.nan_to_num(outs[1][1], nan=-1.0))
     assert outs[0][2] == outs[1][2]
     assert outs[0][2]["live_samples"] < outs[0][2]["sample_slots"]      # there ARE dead slots to skip
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f32x2", "f16"])
+def test_frames_are_bit_stable_across_repeats(hiplib, mlp):
+    """The live-sample list is filled in the workgroups' arrival order, which differs from run to run; every sample is
+    computed on its own lane and written back to its slot, so the frame must not: 12 renders of one frame agree bit for bit."""
+    scene = _scene(128, "fused", mlp_dtype=mlp, smooth_lips=False)     # no EMA state: every render sees the same audio code
+    ref = None
+    with torch.no_grad():
+        for _ in range(12):
+            out = scene.render(2)
+            img, dep = out["image"].clone(), torch.nan_to_num(out["depth"], nan=-1.0).clone()
+            if ref is None:
+                ref = (img, dep)
+            assert torch.equal(img, ref[0]) and torch.equal(dep, ref[1])
