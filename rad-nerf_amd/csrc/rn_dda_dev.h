@@ -27,6 +27,8 @@ __device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade)
 struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
     float rH, H3, bound, dt_gamma, dt_min, dt_max, far, Cf, Hf;
+    float mb1, rmb1;  // one cascade: mip_bound = min(2^0, bound) and its reciprocal are the same for every lattice point
+    bool one_cascade;
     uint32_t H;
     const uint8_t *grid;
 
@@ -42,6 +44,9 @@ struct Dda {
         bound = bound_; dt_gamma = dt_gamma_; far = far_; grid = grid_;
         dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / Hf;        // :386
         dt_min = fminf(dt_max, 2 * kSqrt3 / (float)max_steps);   // :387
+        mb1 = fminf(1.0f, bound_);
+        rmb1 = 1 / mb1;
+        one_cascade = C == 1 && H_ <= 256;  // then level * H3 + (float)morton < 2^24 is exact: no float round trip needed
     }
 
     // occupancy-grid cell of the lattice point at parameter t (raymarching.cu:404-419); returns the bit index.
@@ -56,6 +61,14 @@ struct Dda {
         y = clampf(oy + t * dy, -bound, bound);
         z = clampf(oz + t * dz, -bound, bound);
         dt = clampf(t * dt_gamma, dt_min, dt_max);
+        if (one_cascade) {  // wave-uniform fast path: same arithmetic with the per-ray constants hoisted (level = 0)
+            mip_bound = mb1;
+            const float half_h1 = 0.5f * Hf, top1 = (float)(H - 1);
+            nx = (int)clampf((x * rmb1 + 1) * half_h1, 0.0f, top1);
+            ny = (int)clampf((y * rmb1 + 1) * half_h1, 0.0f, top1);
+            nz = (int)clampf((z * rmb1 + 1) * half_h1, 0.0f, top1);
+            return morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+        }
         int level = 0;
         if (Cf > 1.0f) {  // wave-uniform
             const int lp = mip_from_pos(x, y, z, Cf), ld = mip_from_dt(dt, Hf, Cf);
