@@ -31,14 +31,14 @@ namespace rn {
 #define RN_FUSED_PAIR_HASHED 0
 #endif
 #ifndef RN_F32_XYZ_GROUP
-#define RN_F32_XYZ_GROUP 2
+#define RN_F32_XYZ_GROUP 1
 #endif
 #ifndef RN_F32_AMB_GROUP
-#define RN_F32_AMB_GROUP 4
+#define RN_F32_AMB_GROUP 2
 #endif
 constexpr int kXyzGroup = RN_F32_XYZ_GROUP, kAmbGroup = RN_F32_AMB_GROUP;  // gather rounds in flight per wave (divide 8)
 #ifndef RN_F32_WAVES
-#define RN_F32_WAVES 8
+#define RN_F32_WAVES 12
 #endif
 constexpr int kF32Waves = RN_F32_WAVES, kF32Threads = kF32Waves * kWave;  // 3 waves per SIMD (accumulators: 3 x 32 VGPRs), one workgroup per CU
 constexpr bool kPairHashed = RN_FUSED_PAIR_HASHED;  // aligned x-pair loads on hashed levels inside the fused kernels
