@@ -10,8 +10,8 @@
 //    B operand of an MFMA step (no cross-lane move) and a grid costs 8 rounds, not 16 levels, of latency.
 //  * a 32x32 accumulator has the sample on the lane and the output row on the register index, i.e. it already IS the
 //    B operand of the next layer (k order permuted -- the weight image is packed in that order once, on the device).
-//  * all weights (95.7 KB fp32) sit in LDS for the lifetime of a persistent 512-thread workgroup (one per CU, two
-//    waves per SIMD).  fp32 MFMA and fp32 VALU work share the FMA rate of a SIMD ("where the time goes"),
+//  * all weights (95.7 KB fp32) sit in LDS for the lifetime of a persistent 768-thread workgroup (one per CU, three
+//    waves per SIMD: 3 x 32 accumulator VGPRs leave room for that).  fp32 MFMA and fp32 VALU work share the FMA rate of a SIMD ("where the time goes"),
 //    so the instruction stream around the MFMAs is kept short: per-level plans (rn_grid_dev.h), one-instruction ReLU.
 //  * the torso pass (k_torso_fused) keeps the older 64-sample form: two column tiles per wave, one
 //    v_permlane32_swap per feature pair to build both B operands.
