@@ -724,6 +724,10 @@ __global__ void k_head_reschedule(int32_t *__restrict__ st, uint32_t schedule_N,
 // Packed torso image: deform L0 (21 steps, freq(x) part) | deform L1 (32 steps) | deform L2 VALU [2][2][32]
 //                     | torso L0 (37 steps x 64: grid 16 + freq 21, 32 rows) | torso L1 (16 steps x 64)
 //                     | torso L2 VALU [4][2][16] | raw broadcast columns for the bias: def [64][54+ind], tor [32][54+ind]
+#ifndef RN_TORSO_GROUP
+#define RN_TORSO_GROUP 2
+#endif
+constexpr int kTorsoGroup = RN_TORSO_GROUP;  // torso-grid levels gathered together (divides 16)
 constexpr int kTStep32 = 64;  // floats per MFMA step of a 32-row layer ([2 h][32 j])
 constexpr int TOFF_D0 = 0;
 constexpr int TOFF_D1 = TOFF_D0 + 21 * kStep;
@@ -907,11 +911,28 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p)
             float in[2] = {(fminf(fmaxf(x0 + dxy[0], -1.0f), 1.0f) + 1.0f) / 2.0f,
                            (fminf(fmaxf(x1 + dxy[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
             const bool ok = on && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
+            // kTorsoGroup levels in flight (the deform net's accumulators are dead by now): the 16 gathers are a latency chain
+            // of one tile, and a torso launch is one tile per wave
+            LevelFetch<TT, 2, 2> f[kTorsoGroup];
 #pragma unroll
-            for (int l = 0; l < 16; l++) {
-                float f0, f1;
-                level_features<TT, 2>(p.gt.table, plan_t[l], in, ok, f0, f1);
-                to_b_operands(f0, f1, bg_[0][l], bg_[1][l]);
+            for (int g = 0; g < 16; g += kTorsoGroup) {
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < kTorsoGroup; i++)
+                        issue_planned<TT, 2, 2, false>(static_cast<const TT *>(p.gt.table), plan_t[g + i], in, f[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < kTorsoGroup; i++) {
+                    float f0 = 0.0f, f1 = 0.0f;
+                    if (ok) {
+                        TT res[2];
+                        TT dummy[1];
+                        blend_level<TT, 2, 2, false>(f[i], 0.0f, res, dummy);
+                        f0 = to_f<TT>(res[0]);
+                        f1 = to_f<TT>(res[1]);
+                    }
+                    to_b_operands(f0, f1, bg_[0][g + i], bg_[1][g + i]);
+                }
             }
         }
         // torso net 136 -> 32 -> 32 -> 4 : a single 32-row tile
