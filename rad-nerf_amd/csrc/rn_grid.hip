@@ -15,6 +15,10 @@
 
 #include <math.h>
 
+#ifndef RN_GRID_PAIR_HASHED
+#define RN_GRID_PAIR_HASHED 1
+#endif
+
 namespace rn {
 
 template <uint32_t D>
@@ -26,6 +30,25 @@ __device__ __forceinline__ bool load_input(const float *__restrict__ inputs, uin
         oob |= (in[d] < 0 || in[d] > 1);  // gridencoder.cu:113-117
     }
     return oob;
+}
+
+// One level of one sample.  The common case (align_corners off, linear interpolation, D = 2 / 3) goes through the per-level
+// plan of rn_grid_dev.h -- the level's facts are wave-uniform here, so plan_level() runs on the scalar unit -- and costs
+// ~115 VALU instructions instead of ~500: the level-major lookup was bound by its instruction stream, not by memory.
+template <typename T, uint32_t D, uint32_t C, bool DYDX>
+__device__ __forceinline__ void encode_one(const T *__restrict__ table, uint32_t off, const float (&in)[D], float scale,
+                                           uint32_t resolution, uint32_t hashmap_size, uint32_t gridtype, bool align_corners,
+                                           uint32_t interp, T (&results)[C], T (&grads)[DYDX ? D * C : 1]) {
+    if constexpr (D == 2 || D == 3) {
+        if (!align_corners && interp == 0) {
+            const LevelPlan lp = plan_level<D>(scale, resolution, off, hashmap_size, gridtype, (uint32_t)(sizeof(T) * C));
+            LevelFetch<T, D, C> f;
+            issue_planned<T, D, C, RN_GRID_PAIR_HASHED != 0, true>(table, lp, in, f);
+            blend_level<T, D, C, DYDX>(f, scale, results, grads);
+            return;
+        }
+    }
+    encode_level<T, D, C, DYDX>(table, off, in, scale, resolution, hashmap_size, gridtype, align_corners, interp, results, grads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -54,8 +77,8 @@ k_grid_fwd_level(const float *__restrict__ inputs, const T *__restrict__ table, 
     } else {
         const uint32_t off = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-        encode_level<T, D, C, DYDX>(table, off, in, lc.scale[level], lc.resolution[level], hashmap_size,
-                                    gridtype, align_corners, interp, results, grads);
+        encode_one<T, D, C, DYDX>(table, off, in, lc.scale[level], lc.resolution[level], hashmap_size,
+                                  gridtype, align_corners, interp, results, grads);
     }
     T *o = (LAYOUT == RN_LAYOUT_LBC) ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;
     store_row_nt<T, C>(o, results);  // +3 % on the hash table; non-temporal LOADS of the coordinates were -9 % (measured)
@@ -89,8 +112,8 @@ k_grid_fwd_sample(const float *__restrict__ inputs, const T *__restrict__ table,
                 for (uint32_t i = 0; i < D * C; i++) grads[i] = from_f<T>(0.0f);
             }
         } else {
-            encode_level<T, D, C, DYDX>(table, off, in, lc.scale[level], lc.resolution[level], next - off,
-                                        gridtype, align_corners, interp, results, grads);
+            encode_one<T, D, C, DYDX>(table, off, in, lc.scale[level], lc.resolution[level], next - off,
+                                      gridtype, align_corners, interp, results, grads);
         }
         T *o = (LAYOUT == RN_LAYOUT_LBC) ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;
         store_row<T, C>(o, results);
