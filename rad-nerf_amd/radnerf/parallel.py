@@ -103,13 +103,18 @@ class LoopHintTooSmall(RuntimeError):
 
 
 class FrameParallelRenderer(_Bookkeeping):
-    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False):
+    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False, gather_every=8):
         """speculate_loop (fused engine): after the first finish() the renderer knows how many loop iterations the
         stream's frames take (device counters) and enqueues that many + 2 per frame instead of max_steps, skipping
         the no-op launches behind them; the device flags any frame for which that was not enough and finish() raises
         LoopHintTooSmall so the caller can render the batch again (never observed on a continuous pose stream)."""
         self.scene, self.rank, self.world, self.dist = scene, rank, world, dist
         self.gather = gather and dist is not None and world > 1
+        # Finished frames leave in batches of `gather_every` (one collective per batch: a frame takes ~1 ms, and a collective
+        # per millisecond would keep an RCCL kernel waiting for CUs that the persistent network kernels occupy entirely).
+        # finish() flushes a partial batch, so every rank issues the same sequence of collectives.
+        self.gather_every = max(1, int(gather_every))
+        self._batch = []
         self.pending = []
         self.frames_u8 = None
         self.speculate_loop = speculate_loop and getattr(scene.opt, "engine", "ops") == "fused"
@@ -147,31 +152,40 @@ class FrameParallelRenderer(_Bookkeeping):
         else:
             u8 = (out["image"].reshape(self.scene.H, self.scene.W, 3) * 255).to(torch.uint8)
         if self.gather:
-            if self.frames_u8 is None:
-                self.frames_u8 = torch.empty((self.world,) + tuple(u8.shape), dtype=torch.uint8, device=u8.device)
-            # async: RCCL runs the gather on its own stream, overlapping the next frame's kernels
-            if self.dist.get_backend() == "nccl":
-                buf = torch.empty_like(self.frames_u8)
-                work = self.dist.all_gather_into_tensor(buf, u8.contiguous(), async_op=True)
-                self.pending.append((work, buf, u8))
-            else:  # gloo gathers host tensors (CPU tests, multi-rank rehearsals on a one-GPU box)
-                send = u8.contiguous().cpu()
-                buf = torch.empty((self.world,) + tuple(send.shape), dtype=torch.uint8)
-                work = self.dist.all_gather(list(buf.unbind(0)), send, async_op=True)
-                self.pending.append((work, buf, send))
+            self._batch.append(u8)
+            if len(self._batch) >= self.gather_every:
+                self._flush()
         self.last_frame = u8
         self._frames_since_finish += 1
         return u8
+
+    def _flush(self):
+        """One collective for the frames collected since the last one: [world, n, H, W, 3] uint8."""
+        if not self._batch:
+            return
+        frames = torch.stack(self._batch, 0)
+        self._batch = []
+        if self.dist.get_backend() == "nccl":
+            # async: RCCL runs the gather on its own stream, overlapping the next frames' kernels
+            buf = torch.empty((self.world,) + tuple(frames.shape), dtype=torch.uint8, device=frames.device)
+            work = self.dist.all_gather_into_tensor(buf, frames, async_op=True)
+        else:  # gloo gathers host tensors (CPU tests, multi-rank rehearsals on a one-GPU box)
+            frames = frames.cpu()
+            buf = torch.empty((self.world,) + tuple(frames.shape), dtype=torch.uint8)
+            work = self.dist.all_gather(list(buf.unbind(0)), frames, async_op=True)
+        self.pending.append((work, buf, frames))
 
     def _render_for_count(self, step):
         self.scene.render(frame_of(step, self.rank, self.world))
 
     def finish(self):
         """Wait for every outstanding gather; returns the gathered [world, H, W, 3] uint8 stacks in step order."""
+        if self.gather:
+            self._flush()
         done = []
         for work, buf, _ in self.pending:
             work.wait()
-            done.append(buf)
+            done.extend(buf[:, i] for i in range(buf.shape[1]))   # per step: [world, H, W, 3]
         if done:
             self.frames_u8 = done[-1]
         self.pending = []

@@ -67,7 +67,7 @@ def _sequential(n_total, n_frames):
     return frames, encs
 
 
-def _worker(rank, world, port, steps, n_frames, ret):
+def _worker(rank, world, port, steps, n_frames, ret, gather_every=8):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -75,7 +75,7 @@ def _worker(rank, world, port, steps, n_frames, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from radnerf.parallel import FrameParallelRenderer, frame_of
     scene = _StandInScene(n_frames)
-    fpr = FrameParallelRenderer(scene, rank, world, dist)
+    fpr = FrameParallelRenderer(scene, rank, world, dist, gather_every=gather_every)
     for s in range(steps):
         fpr.step(s)
     stacks = fpr.finish()
@@ -86,13 +86,13 @@ def _worker(rank, world, port, steps, n_frames, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_frame_parallel_equals_sequential(hiplib, world):
-    steps, n_frames = 4, 16
+@pytest.mark.parametrize("world,steps,gather_every", [(2, 4, 8), (3, 4, 8), (2, 7, 3)])   # (2, 7, 3): two full batches + a partial one
+def test_frame_parallel_equals_sequential(hiplib, world, steps, gather_every):
+    n_frames = 16
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, steps, n_frames, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, steps, n_frames, ret, gather_every), nprocs=world, join=True)
     seq_frames, seq_encs = _sequential(steps * world, n_frames)
     for rank in range(world):
         r = ret[rank]
