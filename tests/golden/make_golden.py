@@ -1,23 +1,30 @@
-"""Generates tests/golden/reference_flow.npz -- run ONLY in the build container (needs /root/reference).
+"""Generates the golden fixtures under tests/golden/ -- run ONLY in the build container (needs /root/reference).
 
-It imports the reference's UNMODIFIED Python control flow (nerf/network.py: AudioNet, AudioAttNet, MLP,
-NeRFNetwork.forward / forward_torso / density / encode_audio; nerf/renderer.py: NeRFRenderer.run_cuda; and
-nerf/utils.py: get_rays, get_bg_coords, convert_poses, get_audio_features) and runs it on CPU on top of
-operator packages backed by the CPU oracle (the reference's own CUDA extensions cannot be built here:
-no nvcc / NVIDIA GPU).  Third-party packages the reference imports at module level but never uses on this
-path (tensorboardX, cv2, trimesh, mcubes, torch_ema, imageio, lpips) are stubbed with empty modules.
+    python tests/golden/make_golden.py            # reference_flow.npz, reference_ops.npz, reference_frames.npz
 
-The outputs pin (a) the oracle's restatement of the PyTorch arithmetic (orc_nerf_forward, orc_torso_forward,
-orc_render_frame: loop policy, compaction order, torso mask / scatter, blend, EMA) and (b) this tree's mirror
-of the network / renderer / ray utilities, against the real reference code.  Only data is committed: inputs,
-expected outputs and parameter checksums -- no reference source text.
+What runs is the reference's OWN Python, imported unmodified from /root/reference:
+  * the operator wrappers raymarching/raymarching.py, gridencoder/grid.py, shencoder/sphere_harmonics.py,
+    freqencoder/freq.py (their padding `M += 128 - M % 128`, the `.item()` trim, the [L,B,C] -> [B,L*C] permute, the
+    autocast cast of the table, the zero-initialised gradients, ...), plus encoding.py and activation.py;
+  * the control flow nerf/network.py (AudioNet, AudioAttNet, MLP, NeRFNetwork.forward / forward_torso / density /
+    encode_audio), nerf/renderer.py (NeRFRenderer.run_cuda, both branches) and nerf/utils.py (get_rays, get_bg_coords,
+    convert_poses, get_audio_features).
+Underneath, the four native modules the wrappers import (`_raymarching_face`, `_gridencoder`, `_shencoder`,
+`_freqencoder`) are objects with the pybind11 signatures computing with the CPU oracle (tests/golden/oracle_backends.py):
+the reference's CUDA sources cannot be built here (no nvcc / NVIDIA GPU).  The wrappers' `.cuda()` hops are stubbed to the
+identity so everything stays on CPU tensors.  Third-party packages the reference imports at module level but never uses
+on this path (tensorboardX, cv2, trimesh, mcubes, torch_ema, imageio, lpips) are empty stub modules.
 
-    python tests/golden/make_golden.py
+So these fixtures pin, with real reference code: the wrapper rules, the loop policy / compaction order / torso mask /
+blend / EMA, the MLP and audio arithmetic and the ray utilities.  The kernel arithmetic inside the vectors is the
+oracle's own (a self-comparison for the oracle; for the HIP path it is the oracle check at the reference's call sites).
+Only data is committed: inputs, expected outputs, parameter checksums -- no reference source text.
 """
 import hashlib
 import os
 import sys
 import types
+import warnings
 
 import numpy as np
 import torch
@@ -25,133 +32,55 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-sys.path.insert(0, os.path.join(ROOT, "rad-nerf_amd"))
+for p in (HERE, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "rad-nerf_amd")):
+    sys.path.insert(0, p)
 
-import pyoracle as po  # noqa: E402
+import cases  # noqa: E402
+import oracle_backends as ob  # noqa: E402
+
+warnings.filterwarnings("ignore", category=FutureWarning)
 
 
 def t2n(x):
     return x.detach().cpu().numpy()
 
 
-# ------------------------------------------------------------------ oracle-backed operator packages (CPU)
-def make_oracle_packages():
-    """Modules named like the reference's extension packages, computing with the oracle on CPU tensors."""
-    import torch.nn as nn
-
-    rm = types.ModuleType("raymarching")
-
-    def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
-        n, f = po.near_far_from_aabb(t2n(rays_o), t2n(rays_d), t2n(aabb), min_near)
-        return torch.from_numpy(n), torch.from_numpy(f)
-
-    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
-                   align=-1, perturb=False, dt_gamma=0, max_steps=1024):
-        M = n_alive * n_step
-        if align > 0:
-            M += align - (M % align)
-        assert not perturb
-        x, d, dl = po.march_rays(n_alive, n_step, t2n(rays_alive), t2n(rays_t), t2n(rays_o), t2n(rays_d), bound, dt_gamma,
-                                 max_steps, C, H, t2n(density_bitfield), t2n(near), t2n(far), np.zeros(n_alive, np.float32), M=M)
-        return torch.from_numpy(x), torch.from_numpy(d), torch.from_numpy(dl)
-
-    def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
-        # in place on the caller's torch tensors (shared memory with the numpy views)
-        po.composite_rays(n_alive, n_step, T_thresh, rays_alive.numpy(), rays_t.numpy(), t2n(sigmas.float()), t2n(rgbs.float()),
-                          t2n(deltas), weights_sum.numpy(), depth.numpy(), image.numpy())
-        return tuple()
-
-    def morton3D(coords):
-        return torch.from_numpy(po.morton3D(t2n(coords)))
-
-    rm.near_far_from_aabb, rm.march_rays, rm.composite_rays, rm.morton3D = near_far_from_aabb, march_rays, composite_rays, morton3D
-    rm.packbits = lambda grid, thresh, bitfield=None: torch.from_numpy(po.packbits(t2n(grid), thresh))
-    rm.morton3D_dilation = lambda grid: torch.from_numpy(po.morton3D_dilation(t2n(grid)))
-
-    ge = types.ModuleType("gridencoder")
-
-    class GridEncoder(nn.Module):
-        def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
-                     log2_hashmap_size=19, desired_resolution=None, gridtype="hash", align_corners=False,
-                     interpolation="linear"):
-            super().__init__()
-            from gridencoder_offsets import level_offsets
-            if desired_resolution is not None:
-                per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-            self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
-            self.per_level_scale, self.base_resolution = per_level_scale, base_resolution
-            self.output_dim = num_levels * level_dim
-            self.gridtype, self.gridtype_id = gridtype, {"hash": 0, "tiled": 1}[gridtype]
-            self.align_corners, self.interp_id = align_corners, 0
-            off = level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
-            self.register_buffer("offsets", torch.from_numpy(off))
-            self.embeddings = nn.Parameter(torch.empty(int(off[-1]), level_dim))
-            self.embeddings.data.uniform_(-1e-4, 1e-4)
-
-        def forward(self, inputs, bound=1):
-            inputs = (inputs + bound) / (2 * bound)
-            x = t2n(inputs.reshape(-1, self.input_dim).float())
-            B = x.shape[0]
-            out, _ = po.grid_encode_forward(x, t2n(self.embeddings), t2n(self.offsets), B, self.input_dim, self.level_dim,
-                                            self.num_levels, float(np.log2(self.per_level_scale)), self.base_resolution,
-                                            False, self.gridtype_id, self.align_corners, 0)
-            return torch.from_numpy(np.ascontiguousarray(out.transpose(1, 0, 2)).reshape(B, -1))
-
-    ge.GridEncoder = GridEncoder
-
-    she = types.ModuleType("shencoder")
-
-    class SHEncoder(nn.Module):
-        def __init__(self, input_dim=3, degree=4):
-            super().__init__()
-            self.input_dim, self.degree, self.output_dim = input_dim, degree, degree ** 2
-
-        def forward(self, inputs, size=1):
-            out, _ = po.sh_encode_forward(t2n((inputs / size).reshape(-1, 3).float()), self.degree)
-            return torch.from_numpy(out)
-
-    she.SHEncoder = SHEncoder
-
-    fe = types.ModuleType("freqencoder")
-
-    class FreqEncoder(nn.Module):
-        def __init__(self, input_dim=3, degree=4):
-            super().__init__()
-            self.input_dim, self.degree, self.output_dim = input_dim, degree, input_dim + input_dim * 2 * degree
-
-        def forward(self, inputs, **kwargs):
-            return torch.from_numpy(po.freq_encode_forward(t2n(inputs.reshape(-1, self.input_dim).float()), self.degree))
-
-    fe.FreqEncoder = FreqEncoder
-    return {"raymarching": rm, "gridencoder": ge, "shencoder": she, "freqencoder": fe}
-
-
 def sha(x):
     return hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
 
 
-def main():
-    # offsets helper without importing this tree's HIP-backed gridencoder package under that name
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gridencoder_offsets", os.path.join(ROOT, "rad-nerf_amd", "gridencoder", "encoder.py"))
-    # encoder.py imports radnerf_hip (ctypes only, loads on CPU); we only need level_offsets from it
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    sys.modules["gridencoder_offsets"] = mod
-
+def install_reference():
+    """Make `import raymarching / gridencoder / shencoder / freqencoder / encoding / activation / nerf.*` resolve to the
+    reference's files, on top of the oracle-backed native modules."""
     for name in ("trimesh", "tensorboardX", "cv2", "mcubes", "imageio", "lpips", "torch_ema"):
         sys.modules[name] = types.ModuleType(name)
     sys.modules["torch_ema"].ExponentialMovingAverage = object
-    pkgs = make_oracle_packages()
-    saved = {k: sys.modules.get(k) for k in pkgs}
-    sys.modules.update(pkgs)
+    sys.modules["_raymarching_face"] = ob.raymarching_backend()
+    sys.modules["_gridencoder"] = ob.gridencoder_backend()
+    sys.modules["_shencoder"] = ob.shencoder_backend()
+    sys.modules["_freqencoder"] = ob.freqencoder_backend()
+    torch.Tensor.cuda = lambda self, *a, **k: self          # raymarching.py:34-35, freq.py:22, ...: stay on the CPU
     sys.path.insert(0, REF)
-    import nerf.network as ref_network      # the reference, unmodified
+    import raymarching
+    import gridencoder
+    import shencoder
+    import freqencoder
+    import encoding
+    import activation
+    import nerf.network as ref_network
     import nerf.utils as ref_utils
+    for mod in (raymarching, gridencoder, shencoder, freqencoder, encoding, activation, ref_network, ref_utils):
+        assert mod.__file__.startswith(REF), mod.__file__
+    # scene setup + inputs come from this tree (pure torch on CPU).  Imported AFTER the reference's packages: this tree's
+    # radnerf/__init__ does `import raymarching`, `from encoding import ...`, which now resolve to the reference's modules
+    # already in sys.modules (its mirror classes are not used here; the scene is handed the reference model).
+    from radnerf.scene import SyntheticScene, default_opt
+    return SyntheticScene, default_opt, raymarching, gridencoder, shencoder, freqencoder, ref_network, ref_utils
 
-    from radnerf.scene import SyntheticScene, default_opt  # scene setup + inputs (this tree; pure torch on CPU)
 
+# ------------------------------------------------------------------------------------------------ reference_flow.npz
+def make_flow(env):
+    SyntheticScene, default_opt, _, _, _, _, ref_network, ref_utils = env
     out = {}
     H = W = 32
     opt = default_opt()
@@ -205,14 +134,234 @@ def main():
         out[f"frame{i}_depth"] = t2n(res["depth"]).reshape(-1)
         out[f"frame{i}_enc_a"] = t2n(m.enc_a)
         out[f"frame{i}_torso_alpha"] = t2n(res["torso_alpha"]).reshape(-1)
+    return out
 
-    np.savez_compressed(os.path.join(HERE, "reference_flow.npz"), **out)
-    print("wrote", os.path.join(HERE, "reference_flow.npz"), {k: getattr(v, "shape", None) for k, v in out.items() if "frame" in k})
-    for k, v in saved.items():
-        if v is None:
-            sys.modules.pop(k, None)
-        else:
-            sys.modules[k] = v
+
+# ------------------------------------------------------------------------------------------------ reference_ops.npz
+def make_ops(env):
+    """The reference's operator wrappers called one by one (the names a caller of the packages sees)."""
+    SyntheticScene, default_opt, rm, gridencoder, shencoder, freqencoder, ref_network, ref_utils = env
+    out = {}
+    opt = default_opt()
+    torch.manual_seed(0)
+    scene = SyntheticScene(H=32, W=32, n_frames=8, device="cpu", opt=opt, model=ref_network.NeRFNetwork(opt))
+    m = scene.model
+    f = scene.frame(3)
+    rays_o, rays_d = f["rays_o"].reshape(-1, 3), f["rays_d"].reshape(-1, 3)
+    N = rays_o.shape[0]
+    bits = m.density_bitfield
+    draw = cases.rm_inputs()
+
+    # -- near/far (raymarching.py:19-49)
+    nears, fars = rm.near_far_from_aabb(rays_o, rays_d, m.aabb_infer, m.min_near)
+    out["nears"], out["fars"] = t2n(nears), t2n(fars)
+
+    # -- inference marcher: the padding rule M += align - M % align, also when M is already aligned (raymarching.py:380-383)
+    alive = torch.arange(N, dtype=torch.int32)
+    x1, d1, dl1 = rm.march_rays(N, 1, alive, nears.clone(), rays_o, rays_d, m.bound, bits, m.cascade, m.grid_size, nears, fars, 128,
+                                False, opt.dt_gamma, opt.max_steps)
+    assert x1.shape[0] == N + 128
+    out["march1_xyzs"], out["march1_dirs"], out["march1_deltas"] = t2n(x1), t2n(d1), t2n(dl1)
+    hit = torch.nonzero(dl1[:N, 0] > 0).reshape(-1).int()
+    n_alive = min(300, hit.numel())
+    alive3 = hit[:n_alive].contiguous()
+    out["march3_alive"] = t2n(alive3)
+    rays_t = nears.clone()
+    x3, d3, dl3 = rm.march_rays(n_alive, 3, alive3, rays_t, rays_o, rays_d, m.bound, bits, m.cascade, m.grid_size, nears, fars, 128,
+                                False, opt.dt_gamma, opt.max_steps)
+    out["march3_xyzs"], out["march3_dirs"], out["march3_deltas"] = t2n(x3), t2n(d3), t2n(dl3)
+    xn, _, _ = rm.march_rays(n_alive, 3, alive3, rays_t, rays_o, rays_d, m.bound, bits, m.cascade, m.grid_size, nears, fars, -1,
+                             False, opt.dt_gamma, opt.max_steps)
+    assert xn.shape[0] == n_alive * 3
+    # -- composite (in place; raymarching.py:415-437) with T_thresh = 1e-4 as run_cuda passes it
+    M3 = x3.shape[0]
+    sig, rgb = draw(M3, lo=0.0, hi=60.0), draw(M3, 3)
+    out["comp_sigmas"], out["comp_rgbs"] = t2n(sig), t2n(rgb)
+    ws, dp, im = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+    alive_c, t_c = alive3.clone(), rays_t.clone()
+    rm.composite_rays(n_alive, 3, alive_c, t_c, sig, rgb, dl3, ws, dp, im, 1e-4)
+    out["comp_weights_sum"], out["comp_depth"], out["comp_image"] = t2n(ws), t2n(dp), t2n(im)
+    out["comp_rays_alive"], out["comp_rays_t"] = t2n(alive_c), t2n(t_c)
+
+    # -- training marcher (raymarching.py:187-281): first-epoch path (.item() trim + pad) and the mean_count path
+    xt, dt_, dlt, rt = rm.march_rays_train(rays_o, rays_d, m.bound, bits, m.cascade, m.grid_size, nears, fars, None, -1, False, 128,
+                                           False, opt.dt_gamma, opt.max_steps)
+    out["train_xyzs"], out["train_dirs"], out["train_deltas"], out["train_rays"] = t2n(xt), t2n(dt_), t2n(dlt), t2n(rt)
+    counter = torch.zeros(2, dtype=torch.int32)
+    mean_count = max(128, int(xt.shape[0] * 0.6))              # too small on purpose: rays at the end are dropped (cu:457)
+    xm, dm, dlm, rmn = rm.march_rays_train(rays_o, rays_d, m.bound, bits, m.cascade, m.grid_size, nears, fars, counter, mean_count,
+                                           False, 128, False, opt.dt_gamma, opt.max_steps)
+    out["trainm_mean_count"] = np.array(mean_count)
+    out["trainm_xyzs"], out["trainm_deltas"], out["trainm_rays"], out["trainm_counter"] = t2n(xm), t2n(dlm), t2n(rmn), t2n(counter)
+    # -- training compositor forward + backward (raymarching.py:284-342)
+    Mt = xt.shape[0]
+    sg = draw(Mt, lo=0.0, hi=40.0).requires_grad_(True)
+    rg = draw(Mt, 3).requires_grad_(True)
+    am = draw(Mt).requires_grad_(True)
+    out["ctrain_sigmas"], out["ctrain_rgbs"], out["ctrain_ambient"] = t2n(sg), t2n(rg), t2n(am)
+    wsum, asum, dep, img = rm.composite_rays_train(sg, rg, am, dlt, rt, 1e-4)
+    g_ws, g_as, g_im = draw(N, lo=-1, hi=1), draw(N, lo=-1, hi=1), draw(N, 3, lo=-1, hi=1)
+    out["ctrain_g_ws"], out["ctrain_g_as"], out["ctrain_g_im"] = t2n(g_ws), t2n(g_as), t2n(g_im)
+    ((wsum * g_ws).sum() + (asum * g_as).sum() + (img * g_im).sum()).backward()
+    out.update(ctrain_weights_sum=t2n(wsum), ctrain_ambient_sum=t2n(asum), ctrain_depth=t2n(dep), ctrain_image=t2n(img),
+               ctrain_grad_sigmas=t2n(sg.grad), ctrain_grad_rgbs=t2n(rg.grad), ctrain_grad_ambient=t2n(am.grad))
+    # -- marcher backward (--train_camera; raymarching.py:264-279)
+    ro, rd = rays_o.clone().requires_grad_(True), rays_d.clone().requires_grad_(True)
+    xb, db, _, _ = rm.march_rays_train(ro, rd, m.bound, bits, m.cascade, m.grid_size, nears, fars, None, -1, False, 128, False,
+                                       opt.dt_gamma, opt.max_steps)
+    gx, gd = draw(xb.shape[0], 3, lo=-1, hi=1), draw(xb.shape[0], 3, lo=-1, hi=1)
+    out["trainb_gx"], out["trainb_gd"] = t2n(gx), t2n(gd)
+    ((xb * gx).sum() + (db * gd).sum()).backward()
+    out["trainb_grad_rays_o"], out["trainb_grad_rays_d"] = t2n(ro.grad), t2n(rd.grad)
+
+    # -- occupancy bookkeeping (raymarching.py:83-181)
+    rng = np.random.default_rng(9)
+    coords = torch.from_numpy(rng.integers(0, 128, (2000, 3)).astype(np.int32))
+    idx = rm.morton3D(coords)
+    out["morton_coords"], out["morton_indices"] = t2n(coords), t2n(idx)
+    out["morton_invert"] = t2n(rm.morton3D_invert(idx))
+    grid = torch.from_numpy(rng.uniform(-1, 3, (2, 16 ** 3)).astype(np.float32))
+    out["occ_grid"] = t2n(grid)
+    out["occ_bits"] = t2n(rm.packbits(grid, 1.0))
+    out["occ_dilated"] = t2n(rm.morton3D_dilation(grid))
+
+    # -- grid encoder (gridencoder/grid.py:24-161)
+    for name in ("hash3d", "tiled2d"):
+        kw, x, grad = cases.grid_case(name)
+        enc = cases.redraw_table(gridencoder.GridEncoder(**kw), 100 + len(name))
+        xin = x.clone().requires_grad_(name == "tiled2d")          # requires_grad -> dy_dx -> grad_inputs (grid.py:156)
+        y = enc(xin, bound=1)
+        (y * grad).sum().backward()
+        out[f"grid_{name}_offsets"] = t2n(enc.offsets)
+        out[f"grid_{name}_out"] = t2n(y)
+        out[f"grid_{name}_grad_table"] = t2n(enc.embeddings.grad)
+        if xin.grad is not None:
+            out[f"grid_{name}_grad_inputs"] = t2n(xin.grad)
+    # autocast rule (grid.py:41-44): half table, half outputs, float32 inputs
+    kw, x, grad = cases.grid_case("half3d")
+    enc = cases.redraw_table(gridencoder.GridEncoder(**kw), 123)
+    torch.set_autocast_enabled(True)
+    try:
+        assert torch.is_autocast_enabled()
+        xin = x.clone().requires_grad_(True)
+        y = enc(xin, bound=1)
+        assert y.dtype == torch.float16
+        (y.float() * grad).sum().backward()
+    finally:
+        torch.set_autocast_enabled(False)
+    out["grid_half3d_out"] = t2n(y.float())
+    out["grid_half3d_grad_table"] = t2n(enc.embeddings.grad)
+    out["grid_half3d_grad_inputs"] = t2n(xin.grad)
+    assert enc.embeddings.grad.dtype == torch.float32 and xin.grad.dtype == torch.float32
+    # total-variation gradient (grid.py:163-184)
+    kw, x, grad = cases.grid_case("tv3d")
+    enc = cases.redraw_table(gridencoder.GridEncoder(**kw), 77)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    enc.grad_total_variation(weight=1e-3, inputs=x, bound=1)
+    out["grid_tv3d_grad"] = t2n(enc.embeddings.grad)
+
+    # -- SH (sphere_harmonics.py:14-86) and frequency (freq.py:15-76) encoders
+    d, g = cases.dir_case()
+    din = d.clone().requires_grad_(True)
+    y = shencoder.SHEncoder(degree=4)(din)
+    (y * g).sum().backward()
+    out["sh_out"], out["sh_grad_inputs"] = t2n(y), t2n(din.grad)
+    for D, deg in ((2, 10), (6, 4)):
+        x, g = cases.freq_case(D, deg)
+        xin = x.clone().requires_grad_(True)
+        y = freqencoder.FreqEncoder(input_dim=D, degree=deg)(xin)
+        (y * g).sum().backward()
+        out[f"freq{D}_out"], out[f"freq{D}_grad_inputs"] = t2n(y), t2n(xin.grad)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- reference_frames.npz
+def make_frames(env):
+    SyntheticScene, default_opt, rm, gridencoder, _, _, ref_network, ref_utils = env
+    out = {}
+    kw = lambda opt: {"dt_gamma": opt.dt_gamma, "max_steps": opt.max_steps}  # noqa: E731
+
+    # ---- BASELINE config[1] in small: 64 x 64, xyz grid = hash, T = 2^19, two frames (EMA)
+    opt = default_opt()
+    torch.manual_seed(0)
+    scene = cases.swap_in_hash19(SyntheticScene, opt, gridencoder.GridEncoder, 64, 64, model=ref_network.NeRFNetwork(opt))
+    m = scene.model
+    assert m.encoder.gridtype == "hash" and m.encoder.embeddings.shape[0] == 6119864
+    out["hash19_table_sha256"] = np.array(sha(t2n(m.encoder.embeddings)))
+    m.enc_a = None
+    for i in (0, 1):
+        f = scene.frame(i)
+        with torch.no_grad():
+            res = m.render(f["rays_o"], f["rays_d"], f["auds"], f["bg_coords"], f["poses"], eye=f["eye"], index=0,
+                           bg_color=f["bg_color"], staged=True, perturb=False, **kw(opt))
+        out[f"hash19_frame{i}_image"] = t2n(res["image"]).reshape(-1, 3)
+        out[f"hash19_frame{i}_depth"] = t2n(res["depth"]).reshape(-1)
+        out[f"hash19_frame{i}_enc_a"] = t2n(m.enc_a)
+    del scene, m
+
+    # ---- BASELINE config[0]: ONE 256 x 256 frame of the shipped model, everything on the CPU
+    opt = default_opt()
+    torch.manual_seed(0)
+    scene = SyntheticScene(H=256, W=256, n_frames=8, device="cpu", opt=opt, model=ref_network.NeRFNetwork(opt))
+    m = scene.model
+    m.enc_a = None
+    f = scene.frame(0)
+    with torch.no_grad():
+        res = m.render(f["rays_o"], f["rays_d"], f["auds"], f["bg_coords"], f["poses"], eye=f["eye"], index=0,
+                       bg_color=f["bg_color"], staged=True, perturb=False, **kw(opt))
+    out["config0_image"] = t2n(res["image"]).reshape(-1, 3)
+    out["config0_depth"] = t2n(res["depth"]).reshape(-1)
+    out["config0_enc_a"] = t2n(m.enc_a)
+
+    # ---- BASELINE config[2] call shape: the TRAIN branch of run_cuda on 4096 rays of that frame (renderer.py:206-223),
+    # head model (torso off, as the head is trained), then backward of a seeded scalar
+    opt = default_opt(torso=False, smooth_lips=False)
+    torch.manual_seed(0)
+    scene = SyntheticScene(H=256, W=256, n_frames=8, device="cpu", opt=opt, model=ref_network.NeRFNetwork(opt))
+    m = scene.model
+    m.train()
+    f = scene.frame(0)
+    px = cases.train_pixels(256 * 256)
+    out["train_px"] = t2n(px)
+    for tag, mean_count in (("first", 0), ("steady", 49152)):
+        m.zero_grad(set_to_none=True)
+        m.mean_count, m.local_step = mean_count, 0
+        m.step_counter.zero_()
+        res = m.render(f["rays_o"][:, px], f["rays_d"][:, px], f["auds"], f["bg_coords"][:, px], f["poses"], eye=f["eye"], index=[0],
+                       bg_color=f["bg_color"][:, px], staged=False, perturb=False, force_all_rays=False, **kw(opt))
+        g = cases.rm_inputs(17)
+        loss = (res["image"].reshape(-1, 3) * g(4096, 3, lo=-1, hi=1)).sum() + (res["weights_sum"] * g(4096, lo=-1, hi=1)).sum() \
+            + (res["ambient"] * g(4096, lo=-1, hi=1)).sum()
+        loss.backward()
+        out[f"train_{tag}_image"] = t2n(res["image"]).reshape(-1, 3)
+        out[f"train_{tag}_depth"] = t2n(res["depth"]).reshape(-1)
+        out[f"train_{tag}_weights_sum"] = t2n(res["weights_sum"])
+        out[f"train_{tag}_ambient"] = t2n(res["ambient"])
+        out[f"train_{tag}_counter"] = t2n(m.step_counter[0])
+        out[f"train_{tag}_loss"] = t2n(loss)
+        for name in ("sigma_net.net.2.weight", "color_net.net.0.weight", "ambient_net.net.0.weight", "audio_net.encoder_fc1.2.weight",
+                     "individual_codes"):
+            p = dict(m.named_parameters())[name]
+            gr = p.grad if name != "individual_codes" else p.grad[:1]
+            out[f"train_{tag}_grad::{name}"] = t2n(gr)
+        for name in ("encoder", "encoder_ambient"):
+            gt = getattr(m, name).embeddings.grad
+            nz = torch.nonzero(gt.abs().sum(1)).reshape(-1)
+            out[f"train_{tag}_gradrows::{name}"] = t2n(nz[::97].int())        # a fixed 1-in-97 sample of the touched rows
+            out[f"train_{tag}_gradvals::{name}"] = t2n(gt[nz[::97]])
+            out[f"train_{tag}_gradsum::{name}"] = np.array([float(gt.double().sum()), float(gt.double().abs().sum()), float(nz.numel())])
+    return out
+
+
+def main():
+    env = install_reference()
+    todo = sys.argv[1:] or ["flow", "ops", "frames"]
+    for name, fn in (("flow", make_flow), ("ops", make_ops), ("frames", make_frames)):
+        if name in todo:
+            out = fn(env)
+            path = os.path.join(HERE, f"reference_{name}.npz")
+            np.savez_compressed(path, **out)
+            print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB,", len(out), "arrays")
 
 
 if __name__ == "__main__":

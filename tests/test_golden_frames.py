@@ -1,0 +1,186 @@
+"""Frame-level golden vectors from the reference's own Python (tests/golden/reference_frames.npz; generator:
+tests/golden/make_golden.py -- the UNMODIFIED nerf/network.py, nerf/renderer.py, nerf/utils.py AND the unmodified operator
+wrappers, over oracle-backed native modules):
+
+  * BASELINE config[1] in small: two 64 x 64 frames with the xyz grid = hash, T = 2^19 (the reference model with its
+    encoder exchanged for the reference's own GridEncoder(gridtype='hash', log2_hashmap_size=19));
+  * BASELINE config[0]: one 256 x 256 frame of the shipped model;
+  * BASELINE config[2]'s call: the TRAIN branch of run_cuda on 4 096 rays (first-epoch path and mean_count path), outputs
+    and gradients of a seeded scalar.
+
+  CPU : the oracle (orc_render_frame / the oracle operators chained as renderer.py:206-223 chains them) against them;
+  GPU : this tree's mirror on the HIP path (both inference engines; autograd through the HIP backward kernels).
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import cases  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "reference_frames.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD, allow_pickle=False)
+
+
+def _hash19_scene(device, engine="ops", **kw):
+    from gridencoder import GridEncoder
+    from radnerf.scene import SyntheticScene, default_opt
+    scene = cases.swap_in_hash19(SyntheticScene, default_opt(engine=engine, **kw), GridEncoder, 64, 64)
+    if device != "cpu":
+        scene = _to_device(scene, device)
+    return scene
+
+
+def _to_device(scene, device):
+    """A CPU-built SyntheticScene moved to the GPU (the hash19 model is assembled on the CPU so that its seeded values equal
+    the generator's)."""
+    scene.device = torch.device(device)
+    scene.model = scene.model.to(device)
+    for name in ("poses", "poses6", "aud_features", "eye", "bg_coords", "bg_color"):
+        setattr(scene, name, getattr(scene, name).to(device))
+    scene._rays = {}
+    return scene
+
+
+def _oracle_frame(po, scene, f, enc_a):
+    m = scene.model
+    om = po.model_from_module(m)
+    rc = po.render_cfg_from_module(m, scene.opt.dt_gamma, scene.opt.max_steps)
+    n = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    return po.render_frame(om, rc, n(f["rays_o"]), n(f["rays_d"]), enc_a, n(m.individual_codes[0]), n(f["eye"]), n(f["bg_coords"]),
+                           n(f["poses"]), n(m.individual_codes_torso[0]), n(f["bg_color"].reshape(-1, 3)))
+
+
+def _check_frame(img, dep, gold, prefix, rgb_tol, dep_tol):
+    np.testing.assert_allclose(img, gold[f"{prefix}_image"], rtol=0, atol=rgb_tol)
+    ok = ~np.isnan(gold[f"{prefix}_depth"])
+    assert np.array_equal(np.isnan(dep), ~ok)
+    np.testing.assert_allclose(dep[ok], gold[f"{prefix}_depth"][ok], rtol=0, atol=dep_tol)
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU
+def test_oracle_hash19_frames_match_reference(po, gold, hiplib):
+    scene = _hash19_scene("cpu")
+    table = scene.model.encoder.embeddings.detach().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(table).tobytes()).hexdigest() == str(gold["hash19_table_sha256"])
+    for i in (0, 1):
+        img, dep, stats = _oracle_frame(po, scene, scene.frame(i), gold[f"hash19_frame{i}_enc_a"])
+        assert stats["live_samples"] > 10000
+        _check_frame(img, dep, gold, f"hash19_frame{i}", 5e-6, 2e-5)
+
+
+def test_oracle_config0_frame_matches_reference(po, gold, hiplib):
+    from radnerf.scene import SyntheticScene, default_opt
+    scene = SyntheticScene(H=256, W=256, n_frames=8, device="cpu", opt=default_opt())
+    img, dep, stats = _oracle_frame(po, scene, scene.frame(0), gold["config0_enc_a"])
+    assert stats["live_samples"] > 250000
+    _check_frame(img, dep, gold, "config0", 5e-6, 2e-5)
+
+
+def _train_scene(device):
+    from radnerf.scene import SyntheticScene, default_opt
+    return SyntheticScene(H=256, W=256, n_frames=8, device=device, opt=default_opt(torso=False, smooth_lips=False, engine="ops"))
+
+
+def test_oracle_train_branch_matches_reference(po, gold, hiplib):
+    """renderer.py:183-223, 306-311 restated over the oracle operators: near/far on aabb_train -> march_rays_train -> network
+    -> composite_rays_train -> blend."""
+    scene = _train_scene("cpu")
+    m, opt = scene.model, scene.opt
+    f = scene.frame(0)
+    px = torch.from_numpy(gold["train_px"])
+    ro, rd = f["rays_o"][0, px].numpy(), f["rays_d"][0, px].numpy()
+    with torch.no_grad():
+        enc_a = m.encode_audio(f["auds"]).numpy()
+    nears, fars = po.near_far_from_aabb(ro, rd, m.aabb_train.numpy(), m.min_near)
+    N = ro.shape[0]
+    xyzs, dirs, deltas, rays, counter = po.march_rays_train(ro, rd, m.density_bitfield.numpy(), m.bound, opt.dt_gamma, opt.max_steps,
+                                                            m.cascade, m.grid_size, N * opt.max_steps, nears, fars, np.zeros(N, np.float32))
+    assert np.array_equal(counter, gold["train_first_counter"])
+    mm = int(counter[0])
+    mm += 128 - mm % 128
+    om = po.model_from_module(m)
+    sig, rgb, amb = po.nerf_forward(om, xyzs[:mm], dirs[:mm], enc_a, m.individual_codes[0].detach().numpy(), f["eye"].numpy())
+    ws, asum, dep, img = po.composite_rays_train_forward(sig, rgb, np.abs(amb).sum(-1), deltas[:mm], rays, 1e-4)
+    img = np.clip(img + (1 - ws)[:, None] * f["bg_color"][0, px].numpy(), 0, 1)
+    dep = np.clip(dep - nears, 0, None) / (fars - nears)
+    for tag in ("first", "steady"):
+        np.testing.assert_allclose(ws, gold[f"train_{tag}_weights_sum"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(asum, gold[f"train_{tag}_ambient"], rtol=0, atol=2e-5)
+        _check_frame(img, dep, gold, f"train_{tag}", 5e-6, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["ops", "fused"])
+def test_hip_hash19_frames_match_reference(gold, hiplib, engine):
+    scene = _hash19_scene("cuda", engine, ray_engine="torch")
+    for i in (0, 1):
+        with torch.no_grad():
+            out = scene.render(i)
+        np.testing.assert_allclose(scene.model.enc_a.cpu().numpy(), gold[f"hash19_frame{i}_enc_a"], rtol=0, atol=1e-5)
+        _check_frame(out["image"].reshape(-1, 3).cpu().numpy(), out["depth"].reshape(-1).cpu().numpy(), gold, f"hash19_frame{i}",
+                     2e-3, 1e-3)                                   # north-star fp32 bar
+        assert np.abs(out["image"].reshape(-1, 3).cpu().numpy() - gold[f"hash19_frame{i}_image"]).max() <= 5e-5   # achieved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["ops", "fused"])
+def test_hip_config0_frame_matches_reference(gold, hiplib, engine):
+    from radnerf.scene import SyntheticScene, default_opt
+    scene = SyntheticScene(H=256, W=256, n_frames=8, device="cuda", opt=default_opt(engine=engine, ray_engine="torch"))
+    with torch.no_grad():
+        out = scene.render(0)
+    _check_frame(out["image"].reshape(-1, 3).cpu().numpy(), out["depth"].reshape(-1).cpu().numpy(), gold, "config0", 2e-3, 1e-3)
+    assert np.abs(out["image"].reshape(-1, 3).cpu().numpy() - gold["config0_image"]).max() <= 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,mean_count", [("first", 0), ("steady", 49152)])
+def test_hip_train_branch_matches_reference(gold, hiplib, tag, mean_count):
+    scene = _train_scene("cuda")
+    m, opt = scene.model, scene.opt
+    m.train()
+    f = scene.frame(0)
+    px = torch.from_numpy(gold["train_px"]).cuda()
+    m.zero_grad(set_to_none=True)
+    m.mean_count, m.local_step = mean_count, 0
+    m.step_counter.zero_()
+    res = m.render(f["rays_o"][:, px], f["rays_d"][:, px], f["auds"], f["bg_coords"][:, px], f["poses"], eye=f["eye"], index=[0],
+                   bg_color=f["bg_color"][:, px], staged=False, perturb=False, force_all_rays=False, dt_gamma=opt.dt_gamma,
+                   max_steps=opt.max_steps)
+    g = cases.rm_inputs(17)
+    loss = (res["image"].reshape(-1, 3) * g(4096, 3, lo=-1, hi=1).cuda()).sum() + (res["weights_sum"] * g(4096, lo=-1, hi=1).cuda()).sum() \
+        + (res["ambient"] * g(4096, lo=-1, hi=1).cuda()).sum()
+    loss.backward()
+    n = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    assert np.array_equal(n(m.step_counter[0]).astype(np.int32), gold[f"train_{tag}_counter"])
+    np.testing.assert_allclose(n(res["weights_sum"]), gold[f"train_{tag}_weights_sum"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(n(res["ambient"]), gold[f"train_{tag}_ambient"], rtol=0, atol=2e-4)
+    _check_frame(n(res["image"]).reshape(-1, 3), n(res["depth"]).reshape(-1), gold, f"train_{tag}", 5e-5, 2e-4)
+    assert abs(float(loss) - float(gold[f"train_{tag}_loss"])) <= 2e-3 * abs(float(gold[f"train_{tag}_loss"]))
+    params = dict(m.named_parameters())
+    for key in gold.files:
+        if key.startswith(f"train_{tag}_grad::"):
+            name = key.split("::")[1]
+            got = n(params[name].grad if name != "individual_codes" else params[name].grad[:1])
+            want = gold[key]
+            assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-7, (name, np.abs(got - want).max(), np.abs(want).max())
+    for name in ("encoder", "encoder_ambient"):
+        gt = getattr(m, name).embeddings.grad
+        rows = torch.from_numpy(gold[f"train_{tag}_gradrows::{name}"]).long().cuda()
+        want = gold[f"train_{tag}_gradvals::{name}"]
+        got = n(gt[rows])
+        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-7, name
+        s, sa, nz = gold[f"train_{tag}_gradsum::{name}"]
+        assert abs(float(gt.double().abs().sum()) - sa) <= 2e-3 * sa
+        assert abs(float((gt.abs().sum(1) > 0).sum()) - nz) <= 0.002 * nz + 2
