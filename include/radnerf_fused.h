@@ -77,7 +77,9 @@ int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const flo
 
 /* NeRFNetwork.forward for M sample slots.  deltas (nullable): when given, slots with deltas[2*i] == 0 are
  * dead (raymarching.cu:982) and skipped -- their outputs are left untouched.  m_dev (nullable): device
- * count of slots, overrides M (M is then only the launch bound).  ambient (nullable): [M,2] output. */
+ * count of slots, overrides M (M is then only the launch bound).  ambient (nullable): [M,2] output.
+ * rgbs == NULL (dirs may then be NULL too): density query -- NeRFNetwork.density (nerf/network.py:286-325), sigma only; the
+ * fp32 kernel then skips the geo_feat layer, the SH basis and the colour network (a third of its matrix instructions). */
 int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *deltas, uint32_t M,
                           const int32_t *m_dev, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb,
                           const float *packed, const float *bias, float bound, float *sigmas, float *rgbs,
@@ -167,10 +169,45 @@ int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid
                    const rn_torso_weights_t *w, const float *packed, const rn_grid_t *grid_torso,
                    const float *bg_in, float *bg_out, float *torso_alpha, float *deform, rn_stream_t stream);
 
+/* mask[i] = 1 where the bilinear torso occupancy at bg_coords[i] exceeds `thresh` (F.grid_sample(bilinear, zeros,
+ * align_corners=True) > thresh, nerf/renderer.py:281-283) -- the test rn_torso_fused applies per pixel, exposed for the
+ * differentiable training formulation that gathers those pixels. */
+int rn_torso_mask(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size, float thresh,
+                  uint8_t *mask, rn_stream_t stream);
+
 /* image = clamp(image + (1 - weights_sum) * bg, 0, 1); depth = max(depth - near, 0) / (far - near);
  * optional uint8 quantisation of the frame (image_u8 nullable): floor(image * 255). */
 int rn_blend_frame(float *image, const float *weights_sum, const float *bg, float *depth, const float *nears,
                    const float *fars, uint32_t N, uint8_t *image_u8, rn_stream_t stream);
+
+/* ---- occupancy-grid maintenance -------------------------------------------------------------------
+ * NeRFRenderer.update_extra_state (nerf/renderer.py:383-499) and mark_untrained_grid (:318-379) without the Python block
+ * loops: the cells are enumerated in MORTON order (element i of cascade c = the cell with morton code i), so the sample
+ * buffer of the density query and the density grid share their indexing and nothing is ever scattered.
+ *
+ *   rn_occupancy_points      xyzs[C*H^3, 3]: cell centre (2 c / (H-1) - 1) * (bound_c - bound_c / H) + (u * 2 - 1) * bound_c / H
+ *                            with u from `noise` ([C*H^3, 3] uniform [0,1), torch.rand_like in the reference) or, noise ==
+ *                            NULL, from a counter-based hash of (seed, element index) -- rn_hash_u01_bits() * 2^-24.
+ *   (density query)          rn_nerf_fused_forward(xyzs, NULL, NULL, C*H^3, ..., sigmas, rgbs = NULL, ...): sigma only.
+ *   rn_occupancy_update      tmp = sigmas * density_scale; 6-neighbour max in morton space (raymarching.cu:304-341); where
+ *                            grid >= 0 and tmp >= 0: grid = max(grid * decay, tmp); stats[0] = mean(max(grid, 0)) (summed in
+ *                            double), stats[1] = min(stats[0], density_thresh); bitfield = packbits(grid, stats[1]).
+ *                            workspace: rn_occupancy_workspace(C, H) bytes, ZEROED once by the caller (an arrival counter
+ *                            lives in it; the kernel leaves it zero).  Nothing is read back by the host.
+ *   rn_mark_untrained_grid   grid[c, cell] = -1 for cells no camera sees: poses [n, 4, 4] (pose_stride = 16 floats) or
+ *                            [n, 3, 4] (12) cam2world, intrinsics as the Python floats fx, fy, cx, cy.
+ *   rn_torso_grid_points     xys[H*H, 2] for element i = (column i % H, row i / H) (the transposed index of renderer.py:472);
+ *   rn_torso_grid_update     5 x 5 max pool (-inf padding) of the H*H alphas, grid = max(grid * decay, pooled),
+ *                            stats[0] = mean(grid).  The alphas come from rn_torso_fused(xys, ..., thresh = -1, ...). */
+size_t rn_occupancy_workspace(uint32_t C, uint32_t H);
+int rn_occupancy_points(uint32_t C, uint32_t H, float bound, const float *noise, uint32_t seed, float *xyzs, rn_stream_t stream);
+int rn_occupancy_update(const float *sigmas, float density_scale, float *density_grid, uint32_t C, uint32_t H, float decay,
+                        float density_thresh, uint8_t *bitfield, float *stats, void *workspace, rn_stream_t stream);
+int rn_mark_untrained_grid(const float *poses, uint32_t n_poses, uint32_t pose_stride, double fx, double fy, double cx, double cy,
+                           uint32_t C, uint32_t H, float bound, float *density_grid, rn_stream_t stream);
+int rn_torso_grid_points(uint32_t H, const float *noise, uint32_t seed, float *xys, rn_stream_t stream);
+int rn_torso_grid_update(const float *alphas, float *density_grid_torso, uint32_t H, float decay, float *stats, rn_stream_t stream);
+uint32_t rn_hash_u01_bits(uint32_t seed, uint32_t idx);   /* the 24 random bits behind the built-in jitter (host-callable) */
 
 /* ---- audio code ------------------------------------------------------------------------------
  * NeRFNetwork.encode_audio (nerf/network.py:170-185) = AudioNet (nerf/network.py:41-67: 4 x Conv1d(k3, s2, p1) +

@@ -263,6 +263,53 @@ def grid_index(D, Cc, gridtype, align_corners, ch, hashmap_size, resolution, pos
                                     u32(hashmap_size), u32(resolution), _p(pg)))
 
 
+# ----------------------------------------------------------------- occupancy-grid maintenance (orc_occupancy.c)
+
+
+def occupancy_points(Cc, H, bound, noise=None, seed=0):
+    xyzs = np.empty((Cc * H ** 3, 3), np.float32)
+    nz = None if noise is None else _f32(noise)
+    lib().orc_occupancy_points(u32(Cc), u32(H), f32(bound), _p(nz), u32(seed), _p(xyzs))
+    return xyzs
+
+
+def occupancy_update(sigmas, density_scale, grid, Cc, H, decay, density_thresh):
+    """In place on `grid` (float32 [C, H^3]); returns (bitfield uint8 [C*H^3/8], mean_density, threshold)."""
+    assert grid.dtype == np.float32 and grid.flags.c_contiguous and grid.flags.writeable
+    sigmas = _f32(sigmas)
+    bits = np.empty(Cc * H ** 3 // 8, np.uint8)
+    stats = np.zeros(2, np.float32)
+    lib().orc_occupancy_update(_p(sigmas), f32(density_scale), _p(grid), u32(Cc), u32(H), f32(decay), f32(density_thresh), _p(bits),
+                               _p(stats))
+    return bits, float(stats[0]), float(stats[1])
+
+
+def mark_untrained_grid(poses, intrinsic, Cc, H, bound, grid):
+    """In place on `grid`."""
+    assert grid.dtype == np.float32 and grid.flags.c_contiguous and grid.flags.writeable
+    poses = _f32(poses)
+    stride = poses.shape[1] * poses.shape[2]
+    fx, fy, cx, cy = (float(v) for v in intrinsic)
+    lib().orc_mark_untrained_grid(_p(poses), u32(poses.shape[0]), u32(stride), C.c_double(fx), C.c_double(fy), C.c_double(cx),
+                                  C.c_double(cy), u32(Cc), u32(H), f32(bound), _p(grid))
+
+
+def torso_grid_points(H, noise=None, seed=0):
+    xys = np.empty((H * H, 2), np.float32)
+    nz = None if noise is None else _f32(noise)
+    lib().orc_torso_grid_points(u32(H), _p(nz), u32(seed), _p(xys))
+    return xys
+
+
+def torso_grid_update(alphas, grid, H, decay):
+    """In place on `grid`; returns mean_density_torso."""
+    assert grid.dtype == np.float32 and grid.flags.c_contiguous and grid.flags.writeable
+    alphas = _f32(alphas)
+    stats = np.zeros(1, np.float32)
+    lib().orc_torso_grid_update(_p(alphas), _p(grid), u32(H), f32(decay), _p(stats))
+    return float(stats[0])
+
+
 # ----------------------------------------------------------------- sh / freq
 
 

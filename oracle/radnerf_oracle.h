@@ -208,6 +208,21 @@ void orc_render_frame(const orc_model_t *m, const orc_render_cfg_t *cfg, const f
                       const float *poses6, const float *ind_code_torso, const float *bg_color,
                       float *image, float *depth, uint64_t *stats);
 
+/* ---------------------------------------------------------------- occupancy-grid maintenance
+ * nerf/renderer.py:318-499 (orc_occupancy.c).  Cells in morton order: element i of cascade c = the cell with morton code i. */
+/* :421-430  probe points; noise [C*H^3, 3] uniform [0,1) (torch.rand_like) or NULL = built-in hash of (seed, index) */
+void orc_occupancy_points(uint32_t C, uint32_t H, float bound, const float *noise, uint32_t seed, float *xyzs);
+/* :437-449  dilation, decayed max on valid cells, mean (double sum), threshold, packbits; stats = {mean, threshold} */
+void orc_occupancy_update(const float *sigmas, float density_scale, float *grid, uint32_t C, uint32_t H, float decay,
+                          float density_thresh, uint8_t *bitfield, float *stats);
+/* :318-379 */
+void orc_mark_untrained_grid(const float *poses, uint32_t n_poses, uint32_t pose_stride, double fx, double fy, double cx,
+                             double cy, uint32_t C, uint32_t H, float bound, float *grid);
+/* :464-476, :482-490 */
+void orc_torso_grid_points(uint32_t H, const float *noise, uint32_t seed, float *xys);
+void orc_torso_grid_update(const float *alphas, float *grid, uint32_t H, float decay, float *stats);
+uint32_t orc_hash_u01_bits(uint32_t seed, uint32_t idx);
+
 /* half <-> float helpers (IEEE round-to-nearest-even), exported for tests */
 uint16_t orc_float_to_half(float f);
 float orc_half_to_float(uint16_t h);

@@ -377,6 +377,10 @@ __global__ void __launch_bounds__(kF32Threads, kF32Waves / 4) k_nerf_fused(Fused
             valu_out<1>(a1, lds + OFF_S2R, h, raw);
             sigma = expf(raw[0]);  // trunc_exp forward (activation.py:9-11)
         }
+        if (!p.rgbs) {  // density query (NeRFNetwork.density, nerf/network.py:286-325): no geo_feat layer, no SH, no colour net
+            if (live && h == 0) p.sigmas[sample] = sigma;
+            continue;
+        }
         acc_zero(a0);
         layer_from_acc(a0, a1, lds + OFF_S2, lane_off);  // geo_feat (no activation)
 
@@ -990,6 +994,17 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p)
     }
 }
 
+// Pixels the torso layer covers: bilinear occupancy of the 2-D torso grid above the threshold (renderer.py:281-283).  Used by
+// the differentiable (training) formulation, which gathers those pixels for the PyTorch layers; inference goes through
+// k_torso_fused, which tests the same expression per pixel.
+__global__ void __launch_bounds__(256)
+k_torso_mask(const float *__restrict__ bg_coords, uint32_t N, const float *__restrict__ grid, uint32_t G, float thresh,
+             uint8_t *__restrict__ mask) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    mask[n] = sample_torso_grid(grid, G, bg_coords[2 * (size_t)n], bg_coords[2 * (size_t)n + 1]) > thresh ? 1 : 0;
+}
+
 // renderer.py:306-311
 __global__ void __launch_bounds__(256)
 k_blend(float *__restrict__ image, const float *__restrict__ weights_sum, const float *__restrict__ bg,
@@ -1116,7 +1131,7 @@ int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *del
                           const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed, const float *bias,
                           float bound, float *sigmas, float *rgbs, float *ambient, int mlp_dtype, rn_stream_t stream) {
     if (M == 0) return RN_OK;
-    RN_REQUIRE(xyzs && dirs && packed && bias && sigmas && rgbs, "nerf_fused_forward: null pointer");
+    RN_REQUIRE(xyzs && packed && bias && sigmas && (dirs || !rgbs), "nerf_fused_forward: null pointer");
     RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "nerf_fused_forward: packed must be 16-byte aligned");
     if (int rc = check_grid(grid_xyz, 3, "nerf_fused_forward(xyz grid)")) return rc;
     if (int rc = check_grid(grid_amb, 2, "nerf_fused_forward(ambient grid)")) return rc;
@@ -1234,6 +1249,15 @@ int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid
     if (grid_torso->dtype == RN_F32) hipLaunchKernelGGL((k_torso_fused<float>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
     else hipLaunchKernelGGL((k_torso_fused<__half>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
     return check_launch("torso_fused");
+}
+
+int rn_torso_mask(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size, float thresh,
+                  uint8_t *mask, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
+    RN_REQUIRE(bg_coords && density_grid_torso && mask && grid_size >= 2, "torso_mask: bad arguments");
+    hipLaunchKernelGGL(k_torso_mask, dim3(div_up(N, 256)), dim3(256), 0, as_stream(stream), bg_coords, N, density_grid_torso, grid_size,
+                       thresh, mask);
+    return check_launch("torso_mask");
 }
 
 int rn_blend_frame(float *image, const float *weights_sum, const float *bg, float *depth, const float *nears,

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
         {
             float sh[16];
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-            if (live) {
+            if (live && p.dirs) {
                 dx = p.dirs[3 * (size_t)sample]; dy = p.dirs[3 * (size_t)sample + 1]; dz = p.dirs[3 * (size_t)sample + 2];
             }
             sh_basis<4>(dx, dy, dz, sh);
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_nerf_fused_h16(FusedParams
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float x = h ? part[1][c] : part[0][c];
-                    p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-x));
+                    if (p.rgbs) p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-x));   // NULL: density query
                 }
             }
         }

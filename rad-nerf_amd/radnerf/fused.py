@@ -317,6 +317,43 @@ def network_forward(model, xyzs, dirs, enc_a, ind_code, eye, deltas=None, want_a
     return sigmas, rgbs, ambient
 
 
+def density_forward(model, xyzs, enc_a, eye, out=None):
+    """NeRFNetwork.density (nerf/network.py:286-325) through the fused kernel's sigma branch: no geo_feat layer, no SH, no
+    colour network.  xyzs [M,3] -> sigma [M] (written into `out` when given)."""
+    st = _state(model)
+    st.refresh()
+    xyzs = xyzs.contiguous().float()
+    M = xyzs.shape[0]
+    enc_a = enc_a.reshape(-1).contiguous().float()
+    eye_t = eye.reshape(-1).contiguous().float() if eye is not None else st._zero_eye
+    ind = model.individual_codes[0].detach().reshape(-1).contiguous().float() if model.individual_dim > 0 else None
+    hip.call("rn_nerf_frame_bias", C.byref(st.nw), hip.ptr(enc_a), hip.ptr(eye_t), hip.ptr(ind), hip.ptr(st.bias), hip.stream())
+    sigmas = out if out is not None else torch.empty(M, dtype=torch.float32, device=xyzs.device)
+    hip.call("rn_nerf_fused_forward", hip.ptr(xyzs), None, None, M, None, C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed),
+             hip.ptr(st.bias), float(model.bound), hip.ptr(sigmas), None, None, st.mlp_dtype, hip.stream())
+    return sigmas
+
+
+def torso_forward(model, bg_coords, poses6, ind_code_torso, thresh, bg_in=None, bg_out=None, alpha_out=None, deform_out=None):
+    """The torso layer over N pixels (nerf/renderer.py:269-299 + nerf/network.py:188-219): occupancy test against `thresh`,
+    deformation / torso networks, blend over bg_in (None = white).  Returns (bg_out [N,3], alpha_out [N,1])."""
+    st = _state(model)
+    st.refresh()
+    N = bg_coords.shape[0]
+    dev = bg_coords.device
+    bg_coords = bg_coords.contiguous().float()
+    poses6 = poses6.reshape(-1).contiguous().float()
+    ict = ind_code_torso.detach().reshape(-1).contiguous().float() if ind_code_torso is not None else None
+    if bg_out is None:
+        bg_out = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    if alpha_out is None:
+        alpha_out = torch.empty(N, 1, dtype=torch.float32, device=dev)
+    hip.call("rn_torso_fused", hip.ptr(bg_coords), N, hip.ptr(model.density_grid_torso), int(model.grid_size), float(thresh),
+             hip.ptr(poses6), hip.ptr(ict), float(model.opt.torso_shrink), C.byref(st.tw), hip.ptr(st.tpacked), C.byref(st.gt),
+             hip.ptr(bg_in), hip.ptr(bg_out), hip.ptr(alpha_out), hip.ptr(deform_out), hip.stream())
+    return bg_out, alpha_out
+
+
 def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, ind_code_torso, bg_color, dt_gamma,
                  max_steps, T_thresh, want_u8=False):
     """Inference frame: returns dict(image [N,3], depth [N], weights_sum [N], nears, fars[, image_u8])."""
@@ -393,14 +430,7 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     bg_final = bg_in
     if model.torso:
         thresh = min(model.density_thresh_torso, model.mean_density_torso)
-        ict = ind_code_torso.detach().reshape(-1).contiguous().float() if ind_code_torso is not None else None
-        poses = poses.reshape(-1).contiguous().float()
-        bg_coords = bg_coords.contiguous().float()
-        talpha = torch.empty(N, 1, dtype=torch.float32, device=dev)
-        bg_final = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        hip.call("rn_torso_fused", hip.ptr(bg_coords), N, hip.ptr(model.density_grid_torso), int(model.grid_size),
-                 float(thresh), hip.ptr(poses), hip.ptr(ict), float(model.opt.torso_shrink), C.byref(st.tw),
-                 hip.ptr(st.tpacked), C.byref(st.gt), hip.ptr(bg_in), hip.ptr(bg_final), hip.ptr(talpha), None, s)
+        bg_final, talpha = torso_forward(model, bg_coords, poses, ind_code_torso, thresh, bg_in=bg_in)
         results["torso_alpha"] = talpha
         results["torso_color"] = bg_final
 

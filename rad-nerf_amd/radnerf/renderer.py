@@ -1,16 +1,19 @@
-"""Occupancy-grid renderer -- host-side mirror of the reference's nerf/renderer.py (NeRFRenderer).
+"""Occupancy-grid renderer: the host side of the render path, with the reference's NeRFRenderer contract
+(nerf/renderer.py:63-537) -- the `opt` fields it reads, the registered buffers / parameters and their names
+(aabb_train, aabb_infer, density_grid, density_bitfield, density_grid_torso, step_counter, individual_codes[_torso],
+camera_dR / camera_dT), `render(...) -> dict(image, depth, ...)`, `run_cuda(...)`, `update_extra_state`,
+`mark_untrained_grid`, `reset_extra_state`.
 
-Keeps the reference's public contract: constructor reading the same `opt` fields, the same
-registered buffers / parameters (aabb_train, aabb_infer, density_grid, density_bitfield,
-density_grid_torso, step_counter, individual_codes[_torso]), `render(...)` -> dict(image, depth, ...),
-`run_cuda(...)`, `update_extra_state`, `mark_untrained_grid`, `reset_extra_state`.
-
-`run_cuda` has two inference engines selected by `self.engine`:
-  * "ops"   -- the reference's loop shape (nerf/renderer.py:225-262): march -> network -> composite ->
-               boolean-mask compaction, one host sync per iteration, MLPs as torch layers;
-  * "fused" -- the MI355X path (radnerf/fused.py): the whole <=max_steps loop is enqueued without a
-               single host read-back; live-ray counts, n_step policy and sample counts stay on the device.
-Both produce the reference's results (parity tests in tests/).
+How a frame is produced here:
+  * inference, engine "fused" (radnerf/fused.py): one enqueue of the device-resident loop, torso pass and blend -- no host
+    read-back anywhere;
+  * inference, engine "ops": the reference's loop shape over the drop-in operators (march -> network -> composite -> compact,
+    one host sync per iteration), torso layer through the fused torso kernel when the network has its shape;
+  * training: march_rays_train -> network -> composite_rays_train with autograd through the HIP backward kernels; the torso
+    layer gathers the covered pixels (index list from a HIP kernel), runs the PyTorch layers on them and copies the result
+    back by index.
+Occupancy-grid maintenance (`update_extra_state`, `mark_untrained_grid`) is radnerf/occupancy.py: kernels over the cells
+in morton order, no Python block loops.
 """
 import math
 import random
@@ -18,66 +21,83 @@ import random
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 import raymarching
 
+from . import occupancy
 from .rays import convert_poses, get_audio_features
+
+_LIP_SMOOTHING = 0.35     # weight of the previous frame's audio code (nerf/renderer.py:192)
+
+
+def _n_step_policy(n_rays, n_alive):
+    """Samples per live ray of one loop iteration: the fewer rays are left, the more steps each takes (renderer.py:249)."""
+    return max(1, min(8, n_rays // n_alive))
 
 
 class NeRFRenderer(nn.Module):
     def __init__(self, opt):
-        # nerf/renderer.py:63-133
+        # state and its registration order follow nerf/renderer.py:63-133 (seeded construction reproduces the reference's values)
         super().__init__()
         self.opt = opt
-        self.bound = opt.bound
+        self.bound, self.min_near = opt.bound, opt.min_near
+        self.grid_size, self.density_scale = 128, 1
         self.cascade = 1 + math.ceil(math.log2(opt.bound))
-        self.grid_size = 128
-        self.density_scale = 1
-        self.min_near = opt.min_near
-        self.density_thresh = opt.density_thresh
-        self.density_thresh_torso = opt.density_thresh_torso
-        self.exp_eye = opt.exp_eye
-        self.test_train = opt.test_train
-        self.smooth_lips = opt.smooth_lips
-        self.torso = opt.torso
-        self.cuda_ray = opt.cuda_ray
+        self.density_thresh, self.density_thresh_torso = opt.density_thresh, opt.density_thresh_torso
+        self.exp_eye, self.test_train, self.smooth_lips = opt.exp_eye, opt.test_train, opt.smooth_lips
+        self.torso, self.cuda_ray, self.train_camera = opt.torso, opt.cuda_ray, opt.train_camera
         self.engine = getattr(opt, "engine", "ops")
 
-        aabb_train = torch.FloatTensor([-opt.bound, -opt.bound / 2, -opt.bound, opt.bound, opt.bound / 2, opt.bound])
-        self.register_buffer("aabb_train", aabb_train)
-        self.register_buffer("aabb_infer", aabb_train.clone())
+        half = opt.bound / 2        # the head sits in a slab half as high as the cube
+        box = torch.tensor([-opt.bound, -half, -opt.bound, opt.bound, half, opt.bound], dtype=torch.float32)
+        self.register_buffer("aabb_train", box)
+        self.register_buffer("aabb_infer", box.clone())
 
-        self.individual_num = opt.ind_num
-        self.individual_dim = opt.ind_dim
+        self.individual_num, self.individual_dim = opt.ind_num, opt.ind_dim
         if self.individual_dim > 0:
             self.individual_codes = nn.Parameter(torch.randn(self.individual_num, self.individual_dim) * 0.1)
         if self.torso:
             self.individual_dim_torso = opt.ind_dim_torso
             if self.individual_dim_torso > 0:
                 self.individual_codes_torso = nn.Parameter(torch.randn(self.individual_num, self.individual_dim_torso) * 0.1)
-
-        self.train_camera = self.opt.train_camera
         if self.train_camera:
             self.camera_dR = nn.Parameter(torch.zeros(self.individual_num, 3))
             self.camera_dT = nn.Parameter(torch.zeros(self.individual_num, 3))
 
-        self.register_buffer("density_grid", torch.zeros([self.cascade, self.grid_size ** 3]))
-        self.register_buffer("density_bitfield", torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
-        self.mean_density = 0
-        self.iter_density = 0
+        cells = self.cascade * self.grid_size ** 3
+        self.register_buffer("density_grid", torch.zeros(self.cascade, self.grid_size ** 3))
+        self.register_buffer("density_bitfield", torch.zeros(cells // 8, dtype=torch.uint8))
         if self.torso:
-            self.register_buffer("density_grid_torso", torch.zeros([self.grid_size ** 2]))
-        self.mean_density_torso = 0
-
+            self.register_buffer("density_grid_torso", torch.zeros(self.grid_size ** 2))
         self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
-        self.mean_count = 0
-        self.local_step = 0
-
+        self._mean_density = self._mean_density_torso = 0
+        self._mean_density_dev = self._mean_density_torso_dev = None
+        self.iter_density = self.mean_count = self.local_step = 0
         if self.smooth_lips:
             self.enc_a = None
-        self.last_stats = None  # filled by the inference engines: iterations / sample slots of the last frame
-        self.count_samples = False  # when set, the engines also count live samples (costs a device read-back)
+        self.last_stats = None      # iterations / sample slots of the last frame (filled by the inference engines)
+        self.count_samples = False  # the "ops" loop also counts live samples (costs a read-back)
+
+    # mean densities: refreshed on the device, read by the host only when Python needs the number
+    @property
+    def mean_density(self):
+        if self._mean_density_dev is not None:
+            self._mean_density, self._mean_density_dev = float(self._mean_density_dev[0].item()), None
+        return self._mean_density
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self._mean_density, self._mean_density_dev = value, None
+
+    @property
+    def mean_density_torso(self):
+        if self._mean_density_torso_dev is not None:
+            self._mean_density_torso, self._mean_density_torso_dev = float(self._mean_density_torso_dev[0].item()), None
+        return self._mean_density_torso
+
+    @mean_density_torso.setter
+    def mean_density_torso(self, value):
+        self._mean_density_torso, self._mean_density_torso_dev = value, None
 
     def forward(self, x, d):
         raise NotImplementedError()
@@ -87,35 +107,15 @@ class NeRFRenderer(nn.Module):
 
     def reset_extra_state(self):
         # nerf/renderer.py:145-155
-        if not self.cuda_ray:
-            return
-        self.density_grid.zero_()
-        self.mean_density = 0
-        self.iter_density = 0
-        self.step_counter.zero_()
-        self.mean_count = 0
-        self.local_step = 0
+        if self.cuda_ray:
+            self.density_grid.zero_()
+            self.step_counter.zero_()
+            self.mean_density = 0
+            self.iter_density = self.mean_count = self.local_step = 0
 
-    # ------------------------------------------------------------------------------------------
-    def _audio_code(self, auds):
-        """encode_audio + the lip-smoothing EMA (nerf/renderer.py:188-194); stateful across frames."""
-        if self._fused_audio(auds):
-            # one kernel for AudioNet + AudioAttNet, one for the smoothing recurrence (radnerf/audio.py)
-            from . import audio
-            enc_a = audio.encode_windows(self, auds)
-            if self.smooth_lips:
-                enc_a = audio.smooth_(self, enc_a)
-            return enc_a
-        enc_a = self.encode_audio(auds)
-        if enc_a is not None and self.smooth_lips:
-            if self.enc_a is not None:
-                _lambda = 0.35
-                enc_a = _lambda * self.enc_a + (1 - _lambda) * enc_a
-            self.enc_a = enc_a
-        return enc_a
-
+    # ---------------------------------------------------------------------------------------------- audio code
     def fused_audio_enabled(self):
-        """The fused engine also takes the audio code off PyTorch (inference only; --emb ids and odd shapes stay torch)."""
+        """Inference with the fused engine also takes the audio nets off PyTorch (--emb ids and odd shapes stay there)."""
         if self.training or self.engine != "fused" or getattr(self.opt, "audio_engine", "fused") != "fused":
             return False
         ok = getattr(self, "_fused_audio_ok", None)
@@ -125,253 +125,180 @@ class NeRFRenderer(nn.Module):
         return ok
 
     def _fused_audio(self, auds):
-        if auds is None or not self.fused_audio_enabled() or not auds.is_cuda or auds.dtype != torch.float32:
+        if auds is None or not auds.is_cuda or auds.dtype != torch.float32 or not self.fused_audio_enabled():
             return False
         return tuple(auds.shape) == (8 if self.att > 0 else 1, self.audio_in_dim, 16)
 
-    def _march_loop_ops(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps,
-                        T_thresh):
-        """Inference loop in the reference's shape (nerf/renderer.py:227-262)."""
-        N, device = rays_o.shape[0], rays_o.device
-        weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
-        depth = torch.zeros(N, dtype=torch.float32, device=device)
-        image = torch.zeros(N, 3, dtype=torch.float32, device=device)
-        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
-        rays_t = nears.clone()
-        step = iters = slots = 0
-        live = torch.zeros((), dtype=torch.int64, device=device) if self.count_samples else None
-        while step < max_steps:
-            n_alive = rays_alive.shape[0]
-            if n_alive <= 0:
-                break
-            n_step = max(min(N // n_alive, 8), 1)
-            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
-                                                        self.density_bitfield, self.cascade, self.grid_size, nears, fars,
-                                                        128, perturb if step == 0 else False, dt_gamma, max_steps)
-            sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
-            sigmas = self.density_scale * sigmas
-            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
-                                       image, T_thresh)
-            rays_alive = rays_alive[rays_alive >= 0]
-            step += n_step
-            iters += 1
+    def _audio_code(self, auds):
+        """encode_audio, then the running blend of consecutive frames' codes when lips are smoothed (renderer.py:188-194)."""
+        if self._fused_audio(auds):
+            from . import audio
+            code = audio.encode_windows(self, auds)
+            return audio.smooth_(self, code) if self.smooth_lips else code
+        code = self.encode_audio(auds)
+        if code is None or not self.smooth_lips:
+            return code
+        if self.enc_a is not None:
+            code = _LIP_SMOOTHING * self.enc_a + (1 - _LIP_SMOOTHING) * code
+        self.enc_a = code
+        return code
+
+    # ---------------------------------------------------------------------------------------------- head
+    def _head_inference_ops(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps, T_thresh):
+        """The early-terminating loop in the reference's shape (renderer.py:227-262) over the drop-in operators."""
+        n_rays, dev = rays_o.shape[0], rays_o.device
+        acc = dict(weights_sum=torch.zeros(n_rays, device=dev), depth=torch.zeros(n_rays, device=dev),
+                   image=torch.zeros(n_rays, 3, device=dev))
+        alive = torch.arange(n_rays, dtype=torch.int32, device=dev)
+        t = nears.clone()
+        done = iterations = slots = 0
+        live = torch.zeros((), dtype=torch.int64, device=dev) if self.count_samples else None
+        while done < max_steps and alive.numel() > 0:
+            n_alive = alive.numel()
+            n_step = _n_step_policy(n_rays, n_alive)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive, t, rays_o, rays_d, self.bound, self.density_bitfield,
+                                                        self.cascade, self.grid_size, nears, fars, 128, perturb and done == 0,
+                                                        dt_gamma, max_steps)
+            sigmas, rgbs, _ = self(xyzs, dirs, enc_a, ind_code, eye)
+            raymarching.composite_rays(n_alive, n_step, alive, t, self.density_scale * sigmas, rgbs, deltas, acc["weights_sum"],
+                                       acc["depth"], acc["image"], T_thresh)
+            alive = alive[alive >= 0]          # finished rays were marked -1 by the compositor
+            done += n_step
+            iterations += 1
             slots += xyzs.shape[0]
             if live is not None:
                 live += (deltas[:, 0] > 0).sum()
-        self.last_stats = {"iterations": iters, "sample_slots": slots}
+        self.last_stats = {"iterations": iterations, "sample_slots": slots}
         if live is not None:
             self.last_stats["live_samples"] = int(live.item())
-        return weights_sum, depth, image
+        return acc
 
+    def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps):
+        """Train branch (renderer.py:206-223): every sample of every ray, packed; one sample counter per step (ring of 16)."""
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                force_all_rays, dt_gamma, max_steps)
+        sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
+        weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(self.density_scale * sigmas, rgbs,
+                                                                                   ambient.abs().sum(-1), deltas, rays)
+        return dict(weights_sum=weights_sum, ambient=ambient_sum, depth=depth, image=image)
+
+    # ---------------------------------------------------------------------------------------------- torso layer
+    def _torso_layer(self, bg_coords, poses, enc_a, index, background, results):
+        """Background with the 2-D torso layer blended over it (renderer.py:269-302); fills results[torso_*]."""
+        n_px, dev = bg_coords.shape[0], bg_coords.device
+        code = None
+        if self.individual_dim_torso > 0:
+            code = self.individual_codes_torso[index if self.training else 0]
+        thresh = min(self.density_thresh_torso, self.mean_density_torso)
+        if not torch.is_tensor(background):
+            background = torch.full((n_px, 3), float(background), dtype=torch.float32, device=dev)
+        background = background.reshape(-1, 3).float()
+        if background.shape[0] != n_px:
+            background = background.expand(n_px, 3)
+
+        if not torch.is_grad_enabled() and bg_coords.is_cuda:
+            from . import fused
+            if fused.supported(self):
+                out, alpha = fused.torso_forward(self, bg_coords, poses, code, thresh, bg_in=background.contiguous())
+                results["torso_alpha"], results["torso_color"] = alpha, out
+                return out
+        # differentiable formulation: gather the covered pixels, PyTorch layers, copy back by index
+        covered = occupancy.torso_pixels(self, bg_coords, thresh)
+        alpha = torch.zeros(n_px, 1, dtype=torch.float32, device=dev)
+        color = torch.zeros(n_px, 3, dtype=torch.float32, device=dev)
+        if covered.numel() > 0:
+            a, c, deform = self.forward_torso(bg_coords.index_select(0, covered), poses, enc_a, code)
+            alpha = alpha.index_copy(0, covered, a.float())
+            color = color.index_copy(0, covered, c.float())
+            results["deform"] = deform
+        out = color * alpha + background * (1 - alpha)
+        results["torso_alpha"], results["torso_color"] = alpha, out
+        return out
+
+    # ---------------------------------------------------------------------------------------------- frame
     def run_cuda(self, rays_o, rays_d, auds, bg_coords, poses, eye=None, index=0, dt_gamma=0, bg_color=None,
                  perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
         # nerf/renderer.py:158-316.  rays_o, rays_d: [1,N,3]; auds: [8,C,16]; bg_coords: [1,N,2]; poses: [1,6]
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
+        lead = rays_o.shape[:-1]
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
         bg_coords = bg_coords.contiguous().view(-1, 2)
-
         if self.train_camera and (self.training or self.test_train):
             from .rays import euler_angles_to_matrix
-            dT = self.camera_dT[index]
-            dR = euler_angles_to_matrix(self.camera_dR[index] / 180 * np.pi + 1e-8).squeeze(0)
-            rays_o = rays_o + dT
-            rays_d = rays_d @ dR
-
-        N, device = rays_o.shape[0], rays_o.device
-        results = {}
+            rays_o = rays_o + self.camera_dT[index]
+            rays_d = rays_d @ euler_angles_to_matrix(self.camera_dR[index] / 180 * np.pi + 1e-8).squeeze(0)
 
         if not self.training and self.engine == "fused" and not perturb:
-            # MI355X path: the whole frame through the fused C ABI (radnerf/fused.py)
             from . import fused
-            enc_a = self._audio_code(auds)
-            ind_code = self.individual_codes[0] if self.individual_dim > 0 else None
-            ind_code_torso = (self.individual_codes_torso[0] if (self.torso and self.individual_dim_torso > 0) else None)
-            out = fused.render_frame(self, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, ind_code_torso, bg_color,
+            code = self.individual_codes[0] if self.individual_dim > 0 else None
+            code_torso = self.individual_codes_torso[0] if (self.torso and self.individual_dim_torso > 0) else None
+            out = fused.render_frame(self, rays_o, rays_d, self._audio_code(auds), code, eye, bg_coords, poses, code_torso, bg_color,
                                      dt_gamma, max_steps, T_thresh, want_u8=kwargs.get("want_u8", False))
-            results["image"] = out["image"].view(*prefix, 3)
-            results["depth"] = out["depth"].view(*prefix)
-            for key in ("torso_alpha", "torso_color", "image_u8"):
-                if key in out:
-                    results[key] = out[key]
+            results = {k: out[k] for k in ("torso_alpha", "torso_color", "image_u8") if k in out}
+            results["image"], results["depth"] = out["image"].view(*lead, 3), out["depth"].view(*lead)
             return results
 
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer,
-                                                     self.min_near)
-        nears, fars = nears.detach(), fars.detach()
-
+        box = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = (t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
         enc_a = self._audio_code(auds)
-
+        ind_code = None
         if self.individual_dim > 0:
-            ind_code = self.individual_codes[index] if self.training else self.individual_codes[0]
-        else:
-            ind_code = None
+            ind_code = self.individual_codes[index if self.training else 0]
 
+        results = {}
         if self.training:
-            # nerf/renderer.py:206-223
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
-            self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield,
-                                                                    self.cascade, self.grid_size, nears, fars, counter,
-                                                                    self.mean_count, perturb, 128, force_all_rays,
-                                                                    dt_gamma, max_steps)
-            sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
-            sigmas = self.density_scale * sigmas
-            weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient.abs().sum(-1),
-                                                                                      deltas, rays)
-            results["weights_sum"] = weights_sum
-            results["ambient"] = ambient_sum
+            head = self._head_training(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps)
+            results["weights_sum"], results["ambient"] = head["weights_sum"], head["ambient"]
         else:
-            weights_sum, depth, image = self._march_loop_ops(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb,
-                                                             dt_gamma, max_steps, T_thresh)
+            head = self._head_inference_ops(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps, T_thresh)
 
-        if bg_color is None:
-            bg_color = 1
-
+        background = 1 if bg_color is None else bg_color
         if self.torso:
-            # nerf/renderer.py:269-302: blend the 2-D torso layer over the background first
-            if self.individual_dim_torso > 0:
-                ind_code_torso = self.individual_codes_torso[index] if self.training else self.individual_codes_torso[0]
-            else:
-                ind_code_torso = None
-            density_thresh_torso = min(self.density_thresh_torso, self.mean_density_torso)
-            occupancy = F.grid_sample(self.density_grid_torso.view(1, 1, self.grid_size, self.grid_size),
-                                      bg_coords.view(1, -1, 1, 2), align_corners=True).view(-1)
-            mask = occupancy > density_thresh_torso
-            torso_alpha = torch.zeros([N, 1], device=device)
-            torso_color = torch.zeros([N, 3], device=device)
-            if mask.any():
-                torso_alpha_mask, torso_color_mask, deform = self.forward_torso(bg_coords[mask], poses, enc_a, ind_code_torso)
-                torso_alpha[mask] = torso_alpha_mask.float()
-                torso_color[mask] = torso_color_mask.float()
-                results["deform"] = deform
-            bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
-            results["torso_alpha"] = torso_alpha
-            results["torso_color"] = bg_color
-
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        image = image.view(*prefix, 3).clamp(0, 1)
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        results["depth"] = depth.view(*prefix)
-        results["image"] = image
+            background = self._torso_layer(bg_coords, poses, enc_a, index, background, results)
+        elif torch.is_tensor(background):
+            background = background.reshape(-1, 3)
+        transmittance = (1 - head["weights_sum"]).unsqueeze(-1)
+        results["image"] = (head["image"] + transmittance * background).view(*lead, 3).clamp(0, 1)
+        results["depth"] = (torch.clamp(head["depth"] - nears, min=0) / (fars - nears)).view(*lead)
         return results
 
-    # ------------------------------------------------------------------------------------------
+    def render(self, rays_o, rays_d, auds, bg_coords, poses, staged=False, max_ray_batch=4096, **kwargs):
+        # nerf/renderer.py:504-537: with cuda_ray (always on in this fork) a frame is never staged
+        return self.run_cuda(rays_o, rays_d, auds, bg_coords, poses, **kwargs)
+
+    # ---------------------------------------------------------------------------------------------- occupancy grid
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        # nerf/renderer.py:318-379: cells no training camera sees get density -1
-        if not self.cuda_ray:
-            return
-        if isinstance(poses, np.ndarray):
-            poses = torch.from_numpy(poses)
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
-        dev = self.density_bitfield.device
-        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        count = torch.zeros_like(self.density_grid)
-        poses = poses.to(count.device)
-        for xs in axis:
-            for ys in axis:
-                for zs in axis:
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    world_xyzs = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / self.grid_size
-                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                        head = 0
-                        while head < B:
-                            tail = min(head + S, B)
-                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
-                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
-                            mask_z = cam_xyzs[:, :, 2] > 0
-                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask = (mask_z & mask_x & mask_y).sum(0).reshape(-1)
-                            count[cas, indices] += mask
-                            head += S
-        self.density_grid[count == 0] = -1
-
-    def _grid_density(self, xyzs, enc_a, eye):
-        """sigma at the occupancy-grid probe points (nerf/renderer.py:438: self.density(...)['sigma']).  On the GPU the
-        2.1 M-point query goes through the fused network kernel (one launch instead of 2 grid encodes + 6 GEMMs + their
-        glue per chunk; its colour branch runs on a dummy direction and is discarded) unless
-        opt.grid_refresh_engine == "torch"."""
-        if xyzs.is_cuda and getattr(self.opt, "grid_refresh_engine", "fused") == "fused":
-            from . import fused
-            if fused.supported(self):
-                dirs = torch.zeros_like(xyzs)
-                dirs[:, 2] = 1.0
-                ind = self.individual_codes[0] if self.individual_dim > 0 else None
-                return fused.network_forward(self, xyzs.contiguous(), dirs, enc_a, ind, eye, want_ambient=False)[0]
-        return self.density(xyzs, enc_a, eye)["sigma"]
+        """Cells no training camera sees get density -1 (nerf/renderer.py:318-379).  `S` (the reference's block size) is
+        accepted and unused: one kernel covers every cell, cascade and camera."""
+        if self.cuda_ray:
+            occupancy.mark_untrained(self, poses, intrinsic)
 
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        # nerf/renderer.py:383-499: refresh the 3-D occupancy grid (head) or the 2-D one (torso)
+    def update_extra_state(self, decay=0.95, S=128, noise=None):
+        """Refresh the occupancy grid the marchers skip through (nerf/renderer.py:383-499): the 3-D grid + bitfield when the
+        head is trained, the 2-D grid when the torso is.  A random audio window (and eye value / head pose) conditions the
+        query, as in the reference.  `noise`: optional uniform [0,1) numbers for the jitter of the probe points
+        ([C*H^3, 3] head / [H^2, 2] torso) instead of the kernels' own hash -- parity tests pin it."""
         if not self.cuda_ray:
             return
         dev = self.density_bitfield.device
-        rand_idx = random.randint(0, self.aud_features.shape[0] - 1)
-        auds = get_audio_features(self.aud_features, self.att, rand_idx).to(dev)
-        enc_a = self.encode_audio(auds)
-
-        if not self.torso:
-            tmp_grid = torch.zeros_like(self.density_grid)
-            eye = self.eye_area[[rand_idx]].to(dev) if self.exp_eye else None
-            axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            for xs in axis:
-                for ys in axis:
-                    for zs in axis:
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                        for cas in range(self.cascade):
-                            bound = min(2 ** cas, self.bound)
-                            half_grid_size = bound / self.grid_size
-                            cas_xyzs = xyzs * (bound - half_grid_size)
-                            cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-                            sigmas = self._grid_density(cas_xyzs, enc_a, eye).reshape(-1).detach().to(tmp_grid.dtype)
-                            sigmas *= self.density_scale
-                            tmp_grid[cas, indices] = sigmas
-            tmp_grid = raymarching.morton3D_dilation(tmp_grid)
-            valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-            self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-            self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
-            self.iter_density += 1
-            density_thresh = min(self.mean_density, self.density_thresh)
-            self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
-
+        pick = random.randint(0, self.aud_features.shape[0] - 1)
+        enc_a = self.encode_audio(get_audio_features(self.aud_features, self.att, pick).to(dev))
         if self.torso:
-            tmp_grid_torso = torch.zeros_like(self.density_grid_torso)
-            rand_idx = random.randint(0, self.poses.shape[0] - 1)
-            pose = convert_poses(self.poses[[rand_idx]]).to(dev)
-            ind_code = self.individual_codes_torso[[rand_idx]] if self.opt.ind_dim_torso > 0 else None
-            axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            half_grid_size = 1 / self.grid_size
-            for xs in axis:
-                for ys in axis:
-                    xx, yy = torch.meshgrid(xs, ys, indexing="ij")
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1)], dim=-1)
-                    indices = (coords[:, 1] * self.grid_size + coords[:, 0]).long()  # xy transposed on purpose (:472)
-                    xys = (2 * coords.float() / (self.grid_size - 1) - 1) * (1 - half_grid_size)
-                    xys += (torch.rand_like(xys) * 2 - 1) * half_grid_size
-                    alphas, _, _ = self.forward_torso(xys, pose, enc_a, ind_code)
-                    tmp_grid_torso[indices] = alphas.squeeze(1).float()
-            tmp_grid_torso = F.max_pool2d(tmp_grid_torso.view(1, 1, self.grid_size, self.grid_size), kernel_size=5,
-                                          stride=1, padding=2).view(-1)
-            self.density_grid_torso = torch.maximum(self.density_grid_torso * decay, tmp_grid_torso)
-            self.mean_density_torso = torch.mean(self.density_grid_torso).item()
-
-        total_step = min(16, self.local_step)
-        if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            pick = random.randint(0, self.poses.shape[0] - 1)
+            pose6 = convert_poses(self.poses[[pick]]).to(dev)
+            code = self.individual_codes_torso[[pick]] if self.opt.ind_dim_torso > 0 else None
+            self._mean_density_torso_dev = occupancy.refresh_torso(self, enc_a, pose6, code, decay, noise)
+        else:
+            eye = self.eye_area[[pick]].to(dev) if self.exp_eye else None
+            self._mean_density_dev = occupancy.refresh_head(self, enc_a, eye, decay, noise)
+            self.iter_density += 1
+        # sample budget of the next steps: mean of the counters of the steps since the last refresh (renderer.py:496-499)
+        steps = min(16, self.local_step)
+        if steps > 0:
+            self.mean_count = int(self.step_counter[:steps, 0].sum().item() / steps)
         self.local_step = 0
-
-    def render(self, rays_o, rays_d, auds, bg_coords, poses, staged=False, max_ray_batch=4096, **kwargs):
-        # nerf/renderer.py:504-537: with cuda_ray (always on) the frame is never staged
-        return self.run_cuda(rays_o, rays_d, auds, bg_coords, poses, **kwargs)

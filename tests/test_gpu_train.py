@@ -102,7 +102,7 @@ def test_update_extra_state_head(po, hiplib, monkeypatch):
     m = scene.model
     m.aud_features = scene.aud_features
     m.eye_area = torch.full((scene.n_frames, 1), 0.25, device="cuda")
-    monkeypatch.setattr(torch, "rand_like", lambda x, **k: torch.full_like(x, 0.5))   # (rand*2-1) = 0
+    centred = torch.full((128 ** 3, 3), 0.5, device="cuda")                            # (u*2-1) = 0: probe points at the cell centres
     import random
     monkeypatch.setattr(random, "randint", lambda a, b: 2)
     m.density_grid.zero_()
@@ -110,7 +110,7 @@ def test_update_extra_state_head(po, hiplib, monkeypatch):
     m.step_counter.zero_()
     m.step_counter[:3, 0] = torch.tensor([100, 200, 330], dtype=torch.int32)
     with torch.no_grad():
-        m.update_extra_state()
+        m.update_extra_state(noise=centred)
     assert m.mean_count == 210 and m.local_step == 0
     # oracle recomputation
     H = 128
