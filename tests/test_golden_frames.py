@@ -169,19 +169,27 @@ def test_hip_train_branch_matches_reference(gold, hiplib, tag, mean_count):
     _check_frame(n(res["image"]).reshape(-1, 3), n(res["depth"]).reshape(-1), gold, f"train_{tag}", 5e-5, 2e-4)
     assert abs(float(loss) - float(gold[f"train_{tag}_loss"])) <= 2e-3 * abs(float(gold[f"train_{tag}_loss"]))
     params = dict(m.named_parameters())
+    # Parameters downstream of the ambient grid see sums over ~45 k samples in another order (rocBLAS split-K weight-gradient
+    # GEMMs, atomics): 5e-3 of the largest entry.  Parameters UPSTREAM of it (ambient_net, and the audio nets through enc_a) get
+    # their gradient through d(grid)/d(coordinate), which is piecewise constant: a coordinate that differs in its last bits
+    # lands in the neighbouring cell of a fine level and that sample's term changes by O(1) -- the sum is only stable to ~2 %.
     for key in gold.files:
         if key.startswith(f"train_{tag}_grad::"):
             name = key.split("::")[1]
             got = n(params[name].grad if name != "individual_codes" else params[name].grad[:1])
             want = gold[key]
-            # sums over ~45 k samples in another order (rocBLAS split-K weight-gradient GEMMs, atomics): 5e-3 of the largest entry
-            assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max() + 1e-7, (name, np.abs(got - want).max(), np.abs(want).max())
+            tol = 3e-2 if name.startswith(("ambient_net", "audio_")) else 5e-3
+            assert np.abs(got - want).max() <= tol * np.abs(want).max() + 1e-7, (name, np.abs(got - want).max(), np.abs(want).max())
+            cos = float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
+            assert cos > 0.9995, (name, cos)
     for name in ("encoder", "encoder_ambient"):
         gt = getattr(m, name).embeddings.grad
         rows = torch.from_numpy(gold[f"train_{tag}_gradrows::{name}"]).long().cuda()
         want = gold[f"train_{tag}_gradvals::{name}"]
         got = n(gt[rows])
-        assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max() + 1e-7, name
+        # table rows also collect the ambient path's piecewise-constant term (enc_x feeds ambient_net): same ~2 % stability
+        assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max() + 1e-7, name
+        assert float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30)) > 0.9995, name
         s, sa, nz = gold[f"train_{tag}_gradsum::{name}"]
         assert abs(float(gt.double().abs().sum()) - sa) <= 5e-3 * sa
         assert abs(float((gt.abs().sum(1) > 0).sum()) - nz) <= 0.002 * nz + 2
