@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--time-every", type=int, default=8,
                     help="time the dominant kernel's launches (HIP events on its dispatches) on every n-th step of the timed region; "
                          "a timed dispatch costs ~10 us of idle GPU, so timing all of them lowers the frame rate by 5 %%")
+    ap.add_argument("--audio-batch", type=int, default=8,
+                    help="frames whose audio codes / smoothing recurrence / bias blocks are computed together from the resident "
+                         "feature stream (4 launches per batch instead of 4 per frame; 0 = per frame, as a live stream would)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -226,7 +229,7 @@ def main():
             scene.model.sigma_net.net[-1].weight[0].abs_().mul_(80.0)
     tile = args.workload == "tile"
     fpr = (TileParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint) if tile else
-           FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint))
+           FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint, audio_batch=args.audio_batch))
 
     def barrier():
         if dist is not None:

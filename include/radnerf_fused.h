@@ -74,6 +74,9 @@ int rn_nerf_pack_weights(const rn_nerf_weights_t *w, float *packed, rn_stream_t 
 /* Per-frame bias vectors: W0_amb[:,32:] enc_a | W0_sig[:,64] eye | W0_col[:,80:] ind_code  (3 x 64). */
 int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
                        float *bias, rn_stream_t stream);
+/* The same for n frames at once: enc_a [n, audio_dim] -> bias [n, rn_nerf_bias_floats()] (eye / ind_code shared). */
+int rn_nerf_frame_bias_batch(const rn_nerf_weights_t *w, const float *enc_a, uint32_t n, const float *eye, const float *ind_code,
+                             float *bias, rn_stream_t stream);
 
 /* NeRFNetwork.forward for M sample slots.  deltas (nullable): when given, slots with deltas[2*i] == 0 are
  * dead (raymarching.cu:982) and skipped -- their outputs are left untouched.  m_dev (nullable): device
@@ -129,6 +132,24 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream);
  * arithmetic variant of the network kernel (RN_F32 / RN_F32_SPLIT / RN_F16) and must match the packed image. */
 int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
                     const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream);
+/* The same loop with options (flags):
+ *   RN_LOOP_FIRST_MARCHED  iteration first_iter has been marched already (rn_frame_begin marches iteration 0 inside the prologue
+ *                          kernel), so the call starts with the network launch;
+ *   RN_LOOP_CLOSE_FRAME    the call's last compaction is the frame's last: it also does what rn_head_check_done does (flags the
+ *                          frame in state[RN_HEAD_ST_UNFINISHED] when the loop was still active) and leaves both live-sample
+ *                          counters (state[6], state[14]) at zero, which rn_frame_begin relies on. */
+#define RN_LOOP_FIRST_MARCHED 1u
+#define RN_LOOP_CLOSE_FRAME 2u
+int rn_head_iterate_ex(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
+                       const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, uint32_t flags,
+                       rn_stream_t stream);
+/* Frame prologue in ONE launch: ray generation (pose != NULL: get_rays with N = -1, nerf/utils.py:249-333, written to
+ * h->rays_o / h->rays_d, which must then be writable; pose: device pointer to a row-major [3,4] / [4,4] cam2world matrix, W =
+ * image width) + near/far + loop initialisation (= rn_head_begin) + the march of iteration 0 (n_step = 1).  Follow with
+ * rn_head_iterate_ex(..., first_iter = 0, flags = RN_LOOP_FIRST_MARCHED | RN_LOOP_CLOSE_FRAME).  h->state[6] must be zero on
+ * entry (a zeroed state block on first use; afterwards RN_LOOP_CLOSE_FRAME keeps it so). */
+int rn_frame_begin(const rn_head_t *h, const float *pose, float fx, float fy, float cx, float cy, uint32_t W,
+                   rn_stream_t stream);
 /* Step schedule of a SHARD of a frame (tile-parallel rendering, BASELINE config 4).  The reference's policy
  * n_step = max(min(N // n_alive, 8), 1) (nerf/renderer.py:249) uses the ray count and the live count of the whole
  * call; a rank that renders only a band of the image reproduces the whole-frame schedule (and so the whole-frame
@@ -168,6 +189,14 @@ int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid
                    float thresh, const float *poses6, const float *ind_code, float torso_shrink,
                    const rn_torso_weights_t *w, const float *packed, const rn_grid_t *grid_torso,
                    const float *bg_in, float *bg_out, float *torso_alpha, float *deform, rn_stream_t stream);
+
+/* rn_torso_fused + rn_blend_frame in one pass over the pixels (frame epilogue): the blended background never goes to
+ * memory unless bg_out is given (nullable, like torso_alpha). */
+int rn_torso_blend_frame(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size,
+                         float thresh, const float *poses6, const float *ind_code, float torso_shrink,
+                         const rn_torso_weights_t *w, const float *packed, const rn_grid_t *grid_torso, const float *bg_in,
+                         float *bg_out, float *torso_alpha, float *image, const float *weights_sum, float *depth,
+                         const float *nears, const float *fars, uint8_t *image_u8, rn_stream_t stream);
 
 /* mask[i] = 1 where the bilinear torso occupancy at bg_coords[i] exceeds `thresh` (F.grid_sample(bilinear, zeros,
  * align_corners=True) > thresh, nerf/renderer.py:281-283) -- the test rn_torso_fused applies per pixel, exposed for the
@@ -239,6 +268,11 @@ int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint
  * state = state_valid ? lambda * state + (1 - lambda) * enc[i] : enc[i]; state [dim] is updated in place. */
 int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,
                     rn_stream_t stream);
+
+/* The smoothing recurrence with every intermediate state kept: out[i] = state after folding enc[i] (n x dim), `state` is
+ * updated to out[n-1].  Lets a renderer that knows the next n frames' audio compute all their codes in one go. */
+int rn_audio_smooth_seq(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid, float *out,
+                        rn_stream_t stream);
 
 /* ---- ray generation -----------------------------------------------------------------------
  * get_rays for the full image (nerf/utils.py:249-333, N = -1 branch): pixel (row r, column c) -> ray r * W + c with

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_attend(AudioW w, const 
 }
 
 __global__ void k_audio_smooth(const float *__restrict__ enc, uint32_t n, uint32_t dim, float lambda, float *__restrict__ state,
-                               int state_valid) {
+                               int state_valid, float *__restrict__ seq) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= dim) return;
     float s = state[i];
@@ -221,6 +221,7 @@ __global__ void k_audio_smooth(const float *__restrict__ enc, uint32_t n, uint32
         const float e = enc[(size_t)f * dim + i];
         s = valid ? keep * s + take * e : e;
         valid = true;
+        if (seq) seq[(size_t)f * dim + i] = s;     // rn_audio_smooth_seq: every intermediate state
     }
     state[i] = s;
 }
@@ -289,8 +290,17 @@ int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, fl
     if (n == 0) return RN_OK;
     RN_REQUIRE(enc && state && dim >= 1, "audio_smooth: null pointer");
     hipLaunchKernelGGL(k_audio_smooth, dim3(div_up(dim, 64)), dim3(64), 0, as_stream(stream), enc, n, dim, lambda, state,
-                       state_valid);
+                       state_valid, static_cast<float *>(nullptr));
     return check_launch("audio_smooth");
+}
+
+int rn_audio_smooth_seq(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid, float *out,
+                        rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    RN_REQUIRE(enc && state && out && dim >= 1, "audio_smooth_seq: null pointer");
+    hipLaunchKernelGGL(k_audio_smooth, dim3(div_up(dim, 64)), dim3(64), 0, as_stream(stream), enc, n, dim, lambda, state,
+                       state_valid, out);
+    return check_launch("audio_smooth_seq");
 }
 
 }  // extern "C"

@@ -96,6 +96,8 @@ __global__ void __launch_bounds__(kBias) k_frame_bias(RawW w, const float *__res
                                                       const float *__restrict__ eye,
                                                       const float *__restrict__ ind_code, float *__restrict__ bias) {
     const int t = threadIdx.x, row = t & 63;
+    enc_a += (size_t)blockIdx.x * w.audio_dim;      // one workgroup per frame (rn_nerf_frame_bias_batch)
+    bias += (size_t)blockIdx.x * kBias;
     float acc = 0.0f;
     if (t < 64) {
         const float *r = w.amb_w0 + row * (32 + w.audio_dim) + 32;
@@ -556,6 +558,94 @@ k_head_march(const int32_t *__restrict__ st, const int32_t *__restrict__ rays_al
     if (n == 0) { atomicAdd(&stats[RN_HEAD_ST_ITERS], 1); atomicAdd(&stats[RN_HEAD_ST_SLOTS], (int32_t)(n_alive * n_step)); }
 }
 
+// Frame prologue in ONE launch: [ray generation (nerf/utils.py:249-333)] + near/far + loop initialisation + the march of
+// iteration 0.  Slot n of the alive list is handled by lane n from start to end: it builds (or loads) the ray that the list
+// order puts there, intersects it with the box, resets its accumulators and walks it for the first iteration's
+// n_step = max(min(N // N, 8), 1) = 1 sample.  Nothing here depends on another lane's ray, so what used to be three
+// launches (k_get_rays, k_head_begin, k_head_march) and two [N,3] round trips is one pass.
+// state[6] (live-sample count of even iterations) must be zero on entry: the loop's last compaction leaves it zero.
+struct RaySource {
+    const float *pose;    // [3,4] / [4,4] row-major cam2world, or NULL: rays are given
+    float fx, fy, cx, cy;
+    uint32_t W;
+};
+
+__global__ void __launch_bounds__(kLoopBlock)
+k_frame_begin(RaySource rs, float *__restrict__ rays_o, float *__restrict__ rays_d, const float *__restrict__ aabb, uint32_t N,
+              float min_near, uint32_t max_steps, float bound, float dt_gamma, uint32_t C, uint32_t H,
+              const uint8_t *__restrict__ grid, float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ weights_sum,
+              float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+              int32_t *__restrict__ state, uint32_t order_w, float *__restrict__ xyzs, float *__restrict__ dirs,
+              float *__restrict__ deltas, uint32_t *__restrict__ block_live, int32_t *__restrict__ live_slots) {
+    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
+    if (n == 0) {
+        next_state(state, N, N, 0, max_steps);
+        for (int i = 8; i < 16; i++) state[i] = 0;
+        atomicAdd(&state[RN_HEAD_ST_ITERS], 1);
+        atomicAdd(&state[RN_HEAD_ST_SLOTS], (int32_t)N);          // n_alive * n_step = N * 1
+    }
+    uint32_t emitted = 0;
+    if (n < N) {
+        uint32_t ray = n;                                         // alive-list order (see k_head_begin)
+        if (order_w) {
+            const uint32_t t = n >> 6, within = n & 63u, tiles_x = order_w >> 3;
+            ray = ((t / tiles_x) * 8u + (within >> 3)) * order_w + (t % tiles_x) * 8u + (within & 7u);
+        }
+        float o[3], d[3];
+        if (rs.pose) {                                            // same expressions as k_get_rays
+            const uint32_t r = ray / rs.W, c = ray - r * rs.W;
+            const float x = ((float)c + 0.5f - rs.cx) / rs.fx, y = ((float)r + 0.5f - rs.cy) / rs.fy, z = 1.0f;
+            const float norm = sqrtf(x * x + y * y + z * z);
+            const float ux = x / norm, uy = y / norm, uz = z / norm;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                d[k] = ux * rs.pose[k * 4] + uy * rs.pose[k * 4 + 1] + uz * rs.pose[k * 4 + 2];
+                o[k] = rs.pose[k * 4 + 3];
+                rays_d[(size_t)ray * 3 + k] = d[k];
+                rays_o[(size_t)ray * 3 + k] = o[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o[k] = rays_o[(size_t)ray * 3 + k]; d[k] = rays_d[(size_t)ray * 3 + k]; }
+        }
+        // raymarching.cu:91-145
+        const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+        float near = (aabb[0] - o[0]) * rdx, far = (aabb[3] - o[0]) * rdx;
+        if (near > far) { float c = near; near = far; far = c; }
+        float near_y = (aabb[1] - o[1]) * rdy, far_y = (aabb[4] - o[1]) * rdy;
+        if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+        bool miss = (near > far_y || near_y > far);
+        if (!miss) {
+            if (near_y > near) near = near_y;
+            if (far_y < far) far = far_y;
+            float near_z = (aabb[2] - o[2]) * rdz, far_z = (aabb[5] - o[2]) * rdz;
+            if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+            miss = (near > far_z || near_z > far);
+            if (!miss) {
+                if (near_z > near) near = near_z;
+                if (far_z < far) far = far_z;
+                if (near < min_near) near = min_near;
+            }
+        }
+        near = miss ? FLT_MAX : near;
+        far = miss ? FLT_MAX : far;
+        nears[ray] = near; fars[ray] = far;
+        rays_t[ray] = near;
+        rays_alive[n] = (int32_t)ray;
+        weights_sum[ray] = 0.0f; depth[ray] = 0.0f;
+        image[(size_t)ray * 3] = 0.0f; image[(size_t)ray * 3 + 1] = 0.0f; image[(size_t)ray * 3 + 2] = 0.0f;
+        // iteration 0 (k_head_march with n_alive = N, n_step = 1): slot n
+        Dda s;
+        s.init(o, d, bound, dt_gamma, max_steps, C, H, grid, far);
+        float t = near;
+        emitted = s.walk<true>(t, 1u, xyzs + (size_t)n * 3, dirs + (size_t)n * 3, deltas + (size_t)n * 2);
+        if (!emitted) { deltas[(size_t)n * 2] = 0.0f; deltas[(size_t)n * 2 + 1] = 0.0f; }
+    }
+    __shared__ uint32_t sh[kLoopBlock / kWave + 1];
+    const uint32_t total = list_live_slots(emitted, n, state + 6, live_slots, sh);
+    if (threadIdx.x == 0) block_live[blockIdx.x] = total;
+}
+
 // raymarching.cu:942-1029 + per-block survivor counts for the compaction that follows
 __global__ void __launch_bounds__(kLoopBlock)
 k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__restrict__ rays_alive,
@@ -629,13 +719,16 @@ __global__ void __launch_bounds__(kLoopBlock)
 k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps,
                const int32_t *__restrict__ rays_in, int32_t *__restrict__ rays_out,
                const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats,
-               MarchArgs m) {
+               MarchArgs m, uint32_t close_frame) {
     __shared__ uint32_t red[kLoopBlock / kWave];
     __shared__ uint32_t red_live[kLoopBlock / kWave];
     __shared__ uint32_t red_all[kLoopBlock / kWave];
     __shared__ uint32_t wave_off[kLoopBlock / kWave];
     if (!st[4]) {
         if (blockIdx.x == 0 && threadIdx.x < 8) st_next[threadIdx.x] = st[threadIdx.x];
+        // close_frame (last compaction of a frame's loop): both live-sample counters back to zero for the next frame's
+        // prologue; the loop is over, so rn_head_check_done has nothing to flag
+        if (close_frame && blockIdx.x == 0 && threadIdx.x == 0) { stats[6] = 0; stats[8 + 6] = 0; }
         return;
     }
     const uint32_t n_alive = (uint32_t)st[0];
@@ -681,6 +774,10 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
         uint32_t sum = 0;
         for (int w = 0; w < kLoopBlock / kWave; w++) sum += red_live[w];
         if (sum) atomicAdd(&stats[RN_HEAD_ST_LIVE], (int32_t)sum);
+        if (close_frame) {   // what rn_head_check_done does, folded in: was the loop really over after this iteration?
+            if (active_next) atomicAdd(&stats[RN_HEAD_ST_UNFINISHED], 1);
+            stats[6] = 0; stats[8 + 6] = 0;   // no marcher runs after the frame's last compaction
+        }
         if (MARCH && active_next) {
             st_next[5] = (int32_t)n_blocks;  // the partial sums written below are indexed by THIS launch's workgroups
             atomicAdd(&stats[RN_HEAD_ST_ITERS], 1);
@@ -777,6 +874,14 @@ __global__ void __launch_bounds__(256) k_pack_torso(RawT w, float *__restrict__ 
     packed[e] = v;
 }
 
+struct BlendArgs {   // final blend folded into the torso pass (renderer.py:306-311; rn_torso_blend_frame)
+    float *image;
+    const float *weights_sum;
+    float *depth;
+    const float *nears, *fars;
+    uint8_t *u8;
+};
+
 struct TorsoParams {
     const float *bg_coords;
     uint32_t N;
@@ -790,7 +895,22 @@ struct TorsoParams {
     GridArgs gt;
     const float *bg_in;
     float *bg_out, *alpha_out, *deform_out;
+    BlendArgs blend;
 };
+
+// image = clamp(image + (1 - weights_sum) * bg, 0, 1); depth = max(depth - near, 0) / (far - near)  [, uint8 frame]
+__device__ __forceinline__ void blend_pixel(const BlendArgs &b, size_t px, const float (&bg)[3]) {
+    const float w = 1 - b.weights_sum[px];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v = b.image[3 * px + c] + w * bg[c];
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        b.image[3 * px + c] = v;
+        if (b.u8) b.u8[3 * px + c] = (uint8_t)(v * 255.0f);
+    }
+    const float dd = b.depth[px] - b.nears[px];
+    b.depth[px] = fmaxf(dd, 0.0f) / (b.fars[px] - b.nears[px]);
+}
 
 // F.grid_sample(bilinear, zeros, align_corners=True) of the [G,G] torso grid at (gx, gy) (renderer.py:282)
 __device__ __forceinline__ float sample_torso_grid(const float *__restrict__ img, uint32_t G, float gx, float gy) {
@@ -810,7 +930,7 @@ __device__ __forceinline__ float sample_torso_grid(const float *__restrict__ img
     return out;
 }
 
-template <typename TT>
+template <typename TT, bool BLEND>
 __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kTorsoPacked + kTorsoBias + 64];
     __shared__ LevelPlan plan_t[16];
@@ -869,7 +989,8 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p)
         if (in_range && p.bg_in) { bgc[0] = p.bg_in[3 * (size_t)px]; bgc[1] = p.bg_in[3 * (size_t)px + 1]; bgc[2] = p.bg_in[3 * (size_t)px + 2]; }
         if (__ballot(on) == 0ull) {  // no torso pixel in this tile: background passes through
             if (in_range) {
-                p.bg_out[3 * (size_t)px] = bgc[0]; p.bg_out[3 * (size_t)px + 1] = bgc[1]; p.bg_out[3 * (size_t)px + 2] = bgc[2];
+                if (p.bg_out) { p.bg_out[3 * (size_t)px] = bgc[0]; p.bg_out[3 * (size_t)px + 1] = bgc[1]; p.bg_out[3 * (size_t)px + 2] = bgc[2]; }
+                if constexpr (BLEND) blend_pixel(p.blend, px, bgc);
                 if (p.alpha_out) p.alpha_out[px] = 0.0f;
                 if (p.deform_out) { p.deform_out[2 * (size_t)px] = 0.0f; p.deform_out[2 * (size_t)px + 1] = 0.0f; }
             }
@@ -986,8 +1107,14 @@ __global__ void __launch_bounds__(kFusedThreads, 2) k_torso_fused(TorsoParams p)
                 for (int c = 0; c < 3; c++) col[c] = 1.0f / (1.0f + expf(-o4[1 + c]));
             }
             // bg = torso_color * alpha + bg * (1 - alpha)  (renderer.py:299)
+            float bgf[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) p.bg_out[3 * (size_t)px + c] = col[c] * alpha + bgc[c] * (1 - alpha);
+            for (int c = 0; c < 3; c++) bgf[c] = col[c] * alpha + bgc[c] * (1 - alpha);
+            if (p.bg_out) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) p.bg_out[3 * (size_t)px + c] = bgf[c];
+            }
+            if constexpr (BLEND) blend_pixel(p.blend, px, bgf);
             if (p.alpha_out) p.alpha_out[px] = alpha;
             if (p.deform_out) { p.deform_out[2 * (size_t)px] = on ? dxy[0] : 0.0f; p.deform_out[2 * (size_t)px + 1] = on ? dxy[1] : 0.0f; }
         }
@@ -1127,6 +1254,16 @@ int rn_nerf_frame_bias(const rn_nerf_weights_t *w, const float *enc_a, const flo
     return check_launch("nerf_frame_bias");
 }
 
+int rn_nerf_frame_bias_batch(const rn_nerf_weights_t *w, const float *enc_a, uint32_t n, const float *eye, const float *ind_code,
+                             float *bias, rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(bias && (enc_a || w->audio_dim == 0) && (eye || !w->has_eye) && (ind_code || w->ind_dim == 0),
+               "nerf_frame_bias_batch: null pointer");
+    hipLaunchKernelGGL(k_frame_bias, dim3(n), dim3(kBias), 0, as_stream(stream), raw_w(w), enc_a, eye, ind_code, bias);
+    return check_launch("nerf_frame_bias_batch");
+}
+
 int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *deltas, uint32_t M, const int32_t *m_dev,
                           const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed, const float *bias,
                           float bound, float *sigmas, float *rgbs, float *ambient, int mlp_dtype, rn_stream_t stream) {
@@ -1162,8 +1299,8 @@ int rn_head_begin(const rn_head_t *h, rn_stream_t stream) {
     return check_launch("head_begin");
 }
 
-int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
-                    const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream) {
+int rn_head_iterate_ex(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
+                       const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, uint32_t flags, rn_stream_t stream) {
     if (int rc = check_head(h)) return rc;
     RN_REQUIRE(mlp_dtype == RN_F32 || mlp_dtype == RN_F16 || mlp_dtype == RN_F32_SPLIT,
                "head_iterate: mlp_dtype must be RN_F32, RN_F16 or RN_F32_SPLIT");
@@ -1182,7 +1319,7 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
         // A call marches its own first iteration; after that the compaction kernel marches the next iteration itself.
         // The last compaction of a call does not, so that a caller may adjust the schedule between calls
         // (rn_head_reschedule) -- enqueueing the loop one iteration per call reproduces the four-kernel sequence.
-        if (it == first_iter)
+        if (it == first_iter && !(flags & RN_LOOP_FIRST_MARCHED))
             hipLaunchKernelGGL(k_head_march, rgrid, rblock, 0, s, st, alive, h->rays_t, h->rays_o, h->rays_d, h->bound,
                                h->dt_gamma, h->max_steps, h->cascade, h->grid_size, h->bitfield, h->fars, h->xyzs, h->dirs,
                                h->deltas, h->state, block_live[it & 1u], st + 6, h->live_slots);
@@ -1196,12 +1333,31 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
                           h->xyzs, h->dirs, h->deltas, block_live[(it + 1) & 1u], h->live_slots};
         if (it + 1 < first_iter + n_iters)
             hipLaunchKernelGGL(k_head_compact<true>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
-                               h->block_counts, block_live[it & 1u], h->state, m);
+                               h->block_counts, block_live[it & 1u], h->state, m, 0u);
         else
             hipLaunchKernelGGL(k_head_compact<false>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
-                               h->block_counts, block_live[it & 1u], h->state, m);
+                               h->block_counts, block_live[it & 1u], h->state, m, (flags & RN_LOOP_CLOSE_FRAME) ? 1u : 0u);
     }
     return check_launch("head_iterate");
+}
+
+int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
+                    const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, rn_stream_t stream) {
+    return rn_head_iterate_ex(h, grid_xyz, grid_amb, packed, bias, first_iter, n_iters, mlp_dtype, 0u, stream);
+}
+
+int rn_frame_begin(const rn_head_t *h, const float *pose, float fx, float fy, float cx, float cy, uint32_t W, rn_stream_t stream) {
+    if (int rc = check_head(h)) return rc;
+    RN_REQUIRE(!pose || (fx != 0.0f && fy != 0.0f && W >= 1 && h->N % W == 0), "frame_begin: bad intrinsics / image width");
+    uint32_t order_w = h->order_w;
+    if (order_w && (order_w % 8u || h->N % order_w || (h->N / order_w) % 8u)) order_w = 0;
+    const uint32_t nb = div_up(h->N, kLoopBlock) + 1;
+    const RaySource rs{pose, fx, fy, cx, cy, W ? W : 1u};
+    hipLaunchKernelGGL(k_frame_begin, dim3(div_up(h->N, kLoopBlock)), dim3(kLoopBlock), 0, as_stream(stream), rs,
+                       const_cast<float *>(h->rays_o), const_cast<float *>(h->rays_d), h->aabb, h->N, h->min_near, h->max_steps, h->bound,
+                       h->dt_gamma, h->cascade, h->grid_size, h->bitfield, h->nears, h->fars, h->weights_sum, h->depth, h->image,
+                       h->rays_alive_a, h->rays_t, h->state, order_w, h->xyzs, h->dirs, h->deltas, h->block_counts + nb, h->live_slots);
+    return check_launch("frame_begin");
 }
 
 int rn_head_check_done(const rn_head_t *h, uint32_t iters_done, rn_stream_t stream) {
@@ -1236,19 +1392,41 @@ int rn_torso_fused(const float *bg_coords, uint32_t N, const float *density_grid
                    const float *packed, const rn_grid_t *grid_torso, const float *bg_in, float *bg_out,
                    float *torso_alpha, float *deform, rn_stream_t stream) {
     if (N == 0) return RN_OK;
-    RN_REQUIRE(bg_coords && density_grid_torso && poses6 && w && packed && bg_out, "torso_fused: null pointer");
+    RN_REQUIRE(bg_coords && density_grid_torso && poses6 && w && packed && (bg_out || torso_alpha), "torso_fused: null pointer");
     RN_REQUIRE(ind_code || w->ind_dim == 0, "torso_fused: ind_code required when ind_dim > 0");
     RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "torso_fused: packed must be 16-byte aligned");
     if (int rc = check_grid(grid_torso, 2, "torso_fused(torso grid)")) return rc;
     RawT r{w->def_w0, w->def_w1, w->def_w2, w->tor_w0, w->tor_w1, w->tor_w2, w->ind_dim};
     TorsoParams p{bg_coords, N, density_grid_torso, grid_size, thresh, poses6, ind_code, torso_shrink, r, packed,
-                  grid_args(grid_torso), bg_in, bg_out, torso_alpha, deform};
+                  grid_args(grid_torso), bg_in, bg_out, torso_alpha, deform, BlendArgs{}};
     uint32_t blocks = div_up((N + 63u) >> 6, kWavesPerBlock);
     const uint32_t cap = (uint32_t)num_cus() * 2;
     if (blocks > cap) blocks = cap;
-    if (grid_torso->dtype == RN_F32) hipLaunchKernelGGL((k_torso_fused<float>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
-    else hipLaunchKernelGGL((k_torso_fused<__half>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
+    if (grid_torso->dtype == RN_F32) hipLaunchKernelGGL((k_torso_fused<float, false>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_torso_fused<__half, false>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
     return check_launch("torso_fused");
+}
+
+int rn_torso_blend_frame(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size, float thresh,
+                         const float *poses6, const float *ind_code, float torso_shrink, const rn_torso_weights_t *w,
+                         const float *packed, const rn_grid_t *grid_torso, const float *bg_in, float *bg_out, float *torso_alpha,
+                         float *image, const float *weights_sum, float *depth, const float *nears, const float *fars,
+                         uint8_t *image_u8, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
+    RN_REQUIRE(bg_coords && density_grid_torso && poses6 && w && packed, "torso_blend_frame: null pointer");
+    RN_REQUIRE(image && weights_sum && depth && nears && fars, "torso_blend_frame: null frame buffers");
+    RN_REQUIRE(ind_code || w->ind_dim == 0, "torso_blend_frame: ind_code required when ind_dim > 0");
+    RN_REQUIRE(((uintptr_t)packed & 15u) == 0, "torso_blend_frame: packed must be 16-byte aligned");
+    if (int rc = check_grid(grid_torso, 2, "torso_blend_frame(torso grid)")) return rc;
+    RawT r{w->def_w0, w->def_w1, w->def_w2, w->tor_w0, w->tor_w1, w->tor_w2, w->ind_dim};
+    TorsoParams p{bg_coords, N, density_grid_torso, grid_size, thresh, poses6, ind_code, torso_shrink, r, packed,
+                  grid_args(grid_torso), bg_in, bg_out, torso_alpha, nullptr, BlendArgs{image, weights_sum, depth, nears, fars, image_u8}};
+    uint32_t blocks = div_up((N + 63u) >> 6, kWavesPerBlock);
+    const uint32_t cap = (uint32_t)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    if (grid_torso->dtype == RN_F32) hipLaunchKernelGGL((k_torso_fused<float, true>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_torso_fused<__half, true>), dim3(blocks), dim3(kFusedThreads), 0, as_stream(stream), p);
+    return check_launch("torso_blend_frame");
 }
 
 int rn_torso_mask(const float *bg_coords, uint32_t N, const float *density_grid_torso, uint32_t grid_size, float thresh,

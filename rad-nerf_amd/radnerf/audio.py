@@ -24,6 +24,7 @@ _SIGS = {
     "rn_audio_encode_windows": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, _ptr],
     "rn_audio_encode_stream": [C.POINTER(AudioWeightsT), _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_audio_smooth": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr],
+    "rn_audio_smooth_seq": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr, _ptr],
 }
 for _n, _a in _SIGS.items():
     getattr(_lib, _n).argtypes = _a
@@ -112,3 +113,14 @@ def smooth_(model, enc, lam=0.35):
     state = model.enc_a
     hip.call("rn_audio_smooth", hip.ptr(enc), n, dim, float(lam), hip.ptr(state), int(valid), hip.stream())
     return state
+
+
+def smooth_seq_(model, enc, lam=0.35):
+    """Like smooth_, but returns the state after EVERY code: [n, dim_aud] (row i = model.enc_a as frame i would see it)."""
+    n, dim = enc.shape
+    valid = model.enc_a is not None
+    if not valid:
+        model.enc_a = torch.empty(1, dim, dtype=torch.float32, device=enc.device)
+    out = torch.empty(n, dim, dtype=torch.float32, device=enc.device)
+    hip.call("rn_audio_smooth_seq", hip.ptr(enc), n, dim, float(lam), hip.ptr(model.enc_a), int(valid), hip.ptr(out), hip.stream())
+    return out

@@ -62,6 +62,11 @@ _SIGS = {
                               _ptr, _ptr, C.c_int, _ptr],
     "rn_head_begin": [C.POINTER(HeadT), _ptr],
     "rn_head_iterate": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, C.c_int, _ptr],
+    "rn_head_iterate_ex": [C.POINTER(HeadT), C.POINTER(GridT), C.POINTER(GridT), _ptr, _ptr, _u32, _u32, C.c_int, _u32, _ptr],
+    "rn_frame_begin": [C.POINTER(HeadT), _ptr, _f32, _f32, _f32, _f32, _u32, _ptr],
+    "rn_torso_blend_frame": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
+                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_nerf_frame_bias_batch": [C.POINTER(NerfWeightsT), _ptr, _u32, _ptr, _ptr, _ptr, _ptr],
     "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
     "rn_head_check_done": [C.POINTER(HeadT), _u32, _ptr],
     "rn_get_rays": [_ptr, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
@@ -78,6 +83,7 @@ _lib.rn_nerf_packed_floats.restype = C.c_size_t
 _lib.rn_nerf_packed_floats_h16.restype = C.c_size_t
 _lib.rn_nerf_packed_floats_split.restype = C.c_size_t
 RN_F32_SPLIT = 2
+RN_LOOP_FIRST_MARCHED, RN_LOOP_CLOSE_FRAME = 1, 2
 _lib.rn_nerf_bias_floats.restype = C.c_size_t
 _lib.rn_torso_packed_floats.restype = C.c_size_t
 
@@ -354,9 +360,27 @@ def torso_forward(model, bg_coords, poses6, ind_code_torso, thresh, bg_in=None, 
     return bg_out, alpha_out
 
 
+def frame_bias_batch(model, codes, eye, ind_code):
+    """Per-frame bias blocks of n consecutive frames' audio codes [n, audio_dim] -> [n, 192] (one launch)."""
+    st = _state(model)
+    st.refresh()
+    codes = codes.contiguous().float()
+    n = codes.shape[0]
+    eye_t = eye.reshape(-1).contiguous().float() if eye is not None else st._zero_eye
+    ind = ind_code.detach().reshape(-1).contiguous().float() if ind_code is not None else None
+    out = torch.empty(n, int(_lib.rn_nerf_bias_floats()), dtype=torch.float32, device=codes.device)
+    hip.call("rn_nerf_frame_bias_batch", C.byref(st.nw), hip.ptr(codes), n, hip.ptr(eye_t), hip.ptr(ind), hip.ptr(out), hip.stream())
+    return out
+
+
 def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, ind_code_torso, bg_color, dt_gamma,
-                 max_steps, T_thresh, want_u8=False):
-    """Inference frame: returns dict(image [N,3], depth [N], weights_sum [N], nears, fars[, image_u8])."""
+                 max_steps, T_thresh, want_u8=False, ray_source=None, frame_bias=None):
+    """Inference frame: returns dict(image [N,3], depth [N], weights_sum [N], nears, fars[, image_u8]).
+
+    Launches per frame (whole-frame renders): ONE prologue (rays from `ray_source` = (pose [4,4] on the device, intrinsics,
+    W) when given -- rays_o / rays_d are then output buffers --, near/far, loop initialisation, march of iteration 0), per
+    loop iteration {network, composite, compaction + next march}, ONE epilogue (torso pass + blend [+ uint8]); plus the
+    per-frame bias fold unless the caller hands in `frame_bias` (frame_bias_batch)."""
     st = _state(model)
     st.refresh()
     N = rays_o.shape[0]
@@ -364,10 +388,15 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     dev = rays_o.device
     s = hip.stream()
 
-    enc_a = enc_a.reshape(-1).contiguous().float()
-    eye_t = eye.reshape(-1).contiguous().float() if eye is not None else st._zero_eye
-    ind = ind_code.detach().reshape(-1).contiguous().float() if ind_code is not None else None
-    hip.call("rn_nerf_frame_bias", C.byref(st.nw), hip.ptr(enc_a), hip.ptr(eye_t), hip.ptr(ind), hip.ptr(st.bias), s)
+    if frame_bias is None:
+        enc_a = enc_a.reshape(-1).contiguous().float()
+        eye_t = eye.reshape(-1).contiguous().float() if eye is not None else st._zero_eye
+        ind = ind_code.detach().reshape(-1).contiguous().float() if ind_code is not None else None
+        hip.call("rn_nerf_frame_bias", C.byref(st.nw), hip.ptr(enc_a), hip.ptr(eye_t), hip.ptr(ind), hip.ptr(st.bias), s)
+        bias = st.bias
+    else:
+        bias = frame_bias.reshape(-1)
+        assert bias.numel() == st.bias.numel() and bias.is_contiguous() and bias.dtype == torch.float32
 
     weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
     depth = torch.empty(N, dtype=torch.float32, device=dev)
@@ -394,31 +423,44 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
 
     # The whole <= max_steps loop is enqueued without reading anything back: iterations past the end of the loop
     # are no-ops decided on the device (a few microseconds each), so the host can run ahead of the GPU.
-    hip.call("rn_head_begin", C.byref(h), s)
     shard = getattr(model, "shard_schedule", None)
-    if shard is None:
-        n_iters = int(max_steps) if st.loop_hint is None else min(int(max_steps), st.loop_hint)
-        hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias), 0,
-                 n_iters, st.mlp_dtype, s)
-        if n_iters < int(max_steps):
-            hip.call("rn_head_check_done", C.byref(h), n_iters, s)
+    merged = shard is None and getattr(model.opt, "frame_kernels", "merged") == "merged"
+    n_iters = int(max_steps) if st.loop_hint is None else min(int(max_steps), st.loop_hint)
+    if merged:
+        if ray_source is not None:
+            pose, (fx, fy, cx, cy), W = ray_source
+            pose = pose.reshape(-1, 4)[:4].contiguous().float()
+            hip.call("rn_frame_begin", C.byref(h), hip.ptr(pose), float(fx), float(fy), float(cx), float(cy), int(W), s)
+        else:
+            hip.call("rn_frame_begin", C.byref(h), None, 0.0, 0.0, 0.0, 0.0, 0, s)
+        hip.call("rn_head_iterate_ex", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias), 0, n_iters,
+                 st.mlp_dtype, RN_LOOP_FIRST_MARCHED | RN_LOOP_CLOSE_FRAME, s)
     else:
-        # This call renders a shard of a frame (tile-parallel): the step schedule must be the whole frame's, so the
-        # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.
-        group, n_total = shard
-        total = torch.empty(1, dtype=torch.int32, device=dev)
-        n_iters = int(max_steps) if st.loop_hint is None else min(int(max_steps), st.loop_hint)
-        for it in range(n_iters):
-            hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(st.bias),
-                     it, 1, st.mlp_dtype, s)
-            bank = ((it + 1) & 1) * 8
-            total.copy_(st.state[bank:bank + 1])
-            group.all_reduce(total)
-            hip.call("rn_head_reschedule", C.byref(h), it, int(n_total), hip.ptr(total), hip.stream())
+        if ray_source is not None:
+            pose, (fx, fy, cx, cy), W = ray_source
+            pose = pose.reshape(-1, 4)[:4].contiguous().float()
+            hip.call("rn_get_rays", hip.ptr(pose), float(fx), float(fy), float(cx), float(cy), N // int(W), int(W), hip.ptr(rays_o),
+                     hip.ptr(rays_d), s)
+        hip.call("rn_head_begin", C.byref(h), s)
+        if shard is None:
+            hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias), 0,
+                     n_iters, st.mlp_dtype, s)
+        else:
+            # This call renders a shard of a frame (tile-parallel): the step schedule must be the whole frame's, so the
+            # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.
+            group, n_total = shard
+            total = torch.empty(1, dtype=torch.int32, device=dev)
+            for it in range(n_iters):
+                hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias),
+                         it, 1, st.mlp_dtype, s)
+                bank = ((it + 1) & 1) * 8
+                total.copy_(st.state[bank:bank + 1])
+                group.all_reduce(total)
+                hip.call("rn_head_reschedule", C.byref(h), it, int(n_total), hip.ptr(total), hip.stream())
         if n_iters < int(max_steps):
             hip.call("rn_head_check_done", C.byref(h), n_iters, s)
 
-    # torso layer over the background
+    # torso layer over the background, final blend
     bg_in = None
     if torch.is_tensor(bg_color):
         bg_in = bg_color.reshape(-1, 3).contiguous().float()
@@ -427,18 +469,30 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     elif bg_color is not None and float(bg_color) != 1.0:
         bg_in = torch.full((N, 3), float(bg_color), dtype=torch.float32, device=dev)
     results = {}
-    bg_final = bg_in
-    if model.torso:
-        thresh = min(model.density_thresh_torso, model.mean_density_torso)
-        bg_final, talpha = torso_forward(model, bg_coords, poses, ind_code_torso, thresh, bg_in=bg_in)
-        results["torso_alpha"] = talpha
-        results["torso_color"] = bg_final
-
     model.last_stats = LoopStats(st)
-
     u8 = torch.empty(N, 3, dtype=torch.uint8, device=dev) if want_u8 else None
-    hip.call("rn_blend_frame", hip.ptr(image), hip.ptr(weights_sum), hip.ptr(bg_final), hip.ptr(depth), hip.ptr(st.nears),
-             hip.ptr(st.fars), N, hip.ptr(u8), s)
+    if model.torso and merged:
+        thresh = min(model.density_thresh_torso, model.mean_density_torso)
+        keep = getattr(model.opt, "keep_torso_layer", True)      # results["torso_color"] / ["torso_alpha"] (the reference returns them)
+        talpha = torch.empty(N, 1, dtype=torch.float32, device=dev) if keep else None
+        bg_final = torch.empty(N, 3, dtype=torch.float32, device=dev) if keep else None
+        coords = bg_coords.contiguous().float()
+        p6 = poses.reshape(-1).contiguous().float()
+        ict = ind_code_torso.detach().reshape(-1).contiguous().float() if ind_code_torso is not None else None
+        hip.call("rn_torso_blend_frame", hip.ptr(coords), N, hip.ptr(model.density_grid_torso), int(model.grid_size), float(thresh),
+                 hip.ptr(p6), hip.ptr(ict), float(model.opt.torso_shrink), C.byref(st.tw), hip.ptr(st.tpacked), C.byref(st.gt),
+                 hip.ptr(bg_in), hip.ptr(bg_final), hip.ptr(talpha), hip.ptr(image), hip.ptr(weights_sum), hip.ptr(depth),
+                 hip.ptr(st.nears), hip.ptr(st.fars), hip.ptr(u8), s)
+        if keep:
+            results["torso_alpha"], results["torso_color"] = talpha, bg_final
+    else:
+        bg_final = bg_in
+        if model.torso:
+            thresh = min(model.density_thresh_torso, model.mean_density_torso)
+            bg_final, talpha = torso_forward(model, bg_coords, poses, ind_code_torso, thresh, bg_in=bg_in)
+            results["torso_alpha"], results["torso_color"] = talpha, bg_final
+        hip.call("rn_blend_frame", hip.ptr(image), hip.ptr(weights_sum), hip.ptr(bg_final), hip.ptr(depth), hip.ptr(st.nears),
+                 hip.ptr(st.fars), N, hip.ptr(u8), s)
     results.update(image=image, depth=depth, weights_sum=weights_sum, nears=st.nears, fars=st.fars)
     if want_u8:
         results["image_u8"] = u8

@@ -56,7 +56,7 @@ class _Bookkeeping:
             self._frames_since_finish = 0
             raise LoopHintTooSmall(f"{unfinished - prev[1]} frame(s) needed more loop iterations than the hint")
         iters = ((cur[0] - (prev[0][0] if prev else 0)) & 0xFFFFFFFF) / self._frames_since_finish
-        fused.set_loop_hint(m, int(-(-iters // 1)) + 2)
+        fused.set_loop_hint(m, int(-(-iters // 1)) + 1)     # one spare iteration: a no-op iteration is 3 launches, ~10 us
         self._frames_since_finish = 0
 
 
@@ -103,7 +103,7 @@ class LoopHintTooSmall(RuntimeError):
 
 
 class FrameParallelRenderer(_Bookkeeping):
-    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False, gather_every=8):
+    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False, gather_every=8, audio_batch=0):
         """speculate_loop (fused engine): after the first finish() the renderer knows how many loop iterations the
         stream's frames take (device counters) and enqueues that many + 2 per frame instead of max_steps, skipping
         the no-op launches behind them; the device flags any frame for which that was not enough and finish() raises
@@ -120,6 +120,13 @@ class FrameParallelRenderer(_Bookkeeping):
         self.speculate_loop = speculate_loop and getattr(scene.opt, "engine", "ops") == "fused"
         self._frames_since_finish = 0
         self._counters = None
+        # audio_batch = K > 0 (fused engine, a resident feature stream): the audio codes, their smoothing recurrence and the
+        # per-frame bias blocks of this rank's next K frames are computed together -- 4 launches per K frames instead of 4
+        # per frame; the frames then start at the ray prologue.  Same numbers: the recurrence runs over every global frame
+        # in order (the other ranks' included), exactly as _advance_audio does frame by frame.
+        self.audio_batch = max(0, int(audio_batch))
+        self._ab = None                  # (first step, smoothed codes [K, dim], bias blocks [K, 192])
+        self._ab_next = None             # the step the prepared batch expects next
 
     # -- audio state ------------------------------------------------------------------------------
     def _advance_audio(self, frames):
@@ -139,14 +146,45 @@ class FrameParallelRenderer(_Bookkeeping):
             enc = m.encode_audio(get_audio_features(self.scene.aud_features, self.scene.opt.att, g % n))
             m.enc_a = enc if m.enc_a is None else 0.35 * m.enc_a + (1 - 0.35) * enc
 
+    def _audio_batch_ok(self):
+        m, sc = self.scene.model, self.scene
+        return (self.audio_batch > 0 and getattr(m, "fused_audio_enabled", None) is not None and m.smooth_lips and sc.opt.att == 2
+                and sc.n_frames >= 8 and sc.aud_features.is_cuda and sc.aud_features.dtype == torch.float32 and m.fused_audio_enabled())
+
+    def _prepare_audio(self, step):
+        """Codes + bias blocks of this rank's frames at steps step .. step + K - 1 (one stream encode over every global frame
+        from the first one not folded yet, one recurrence, one bias launch)."""
+        from . import audio, fused
+        m, sc, K = self.scene.model, self.scene, self.audio_batch
+        mine = [frame_of(step + j, self.rank, self.world) for j in range(K)]
+        skipped = skipped_frames(step, self.rank, self.world)
+        g0 = skipped[0] if skipped else mine[0]
+        codes = audio.encode_stream(m, sc.aud_features, g0 % sc.n_frames, mine[-1] - g0 + 1)
+        states = audio.smooth_seq_(m, codes)
+        pick = torch.tensor([g - g0 for g in mine], dtype=torch.long, device=states.device)
+        states = states.index_select(0, pick) if len(mine) != states.shape[0] else states
+        code = m.individual_codes[0] if m.individual_dim > 0 else None
+        self._ab = (step, states, fused.frame_bias_batch(m, states, sc.eye, code))
+        self._ab_next = step
+
     # -- one step = one frame on this rank ----------------------------------------------------------
     def step(self, step):
-        self._advance_audio(skipped_frames(step, self.rank, self.world))
         g = frame_of(step, self.rank, self.world)
+        if self._audio_batch_ok():
+            if self._ab is None or step != self._ab_next or step - self._ab[0] >= self._ab[1].shape[0]:
+                self._prepare_audio(step)
+            j = step - self._ab[0]
+            self._ab_next = step + 1
+            out = self.scene.render(g, want_u8=True, audio_code=(self._ab[1][j:j + 1], self._ab[2][j]))
+            return self._after_render(out)
+        self._advance_audio(skipped_frames(step, self.rank, self.world))
         try:
             out = self.scene.render(g, want_u8=True)
         except TypeError:                      # a scene object without the want_u8 option
             out = self.scene.render(g)
+        return self._after_render(out)
+
+    def _after_render(self, out):
         if "image_u8" in out:                  # quantised by the blend kernel itself
             u8 = out["image_u8"].reshape(self.scene.H, self.scene.W, 3)
         else:

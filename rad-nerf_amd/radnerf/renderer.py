@@ -235,8 +235,13 @@ class NeRFRenderer(nn.Module):
             from . import fused
             code = self.individual_codes[0] if self.individual_dim > 0 else None
             code_torso = self.individual_codes_torso[0] if (self.torso and self.individual_dim_torso > 0) else None
-            out = fused.render_frame(self, rays_o, rays_d, self._audio_code(auds), code, eye, bg_coords, poses, code_torso, bg_color,
-                                     dt_gamma, max_steps, T_thresh, want_u8=kwargs.get("want_u8", False))
+            # a caller that knows the coming frames' audio hands in this frame's smoothed code and bias block
+            # (kwargs["audio_code"] = (enc_a [1,64], bias [192]); radnerf/parallel.py), else the per-frame kernels run
+            given = kwargs.get("audio_code")
+            enc_a, frame_bias = given if given is not None else (self._audio_code(auds), None)
+            out = fused.render_frame(self, rays_o, rays_d, enc_a, code, eye, bg_coords, poses, code_torso, bg_color,
+                                     dt_gamma, max_steps, T_thresh, want_u8=kwargs.get("want_u8", False),
+                                     ray_source=kwargs.get("ray_source"), frame_bias=frame_bias)
             results = {k: out[k] for k in ("torso_alpha", "torso_color", "image_u8") if k in out}
             results["image"], results["depth"] = out["image"].view(*lead, 3), out["depth"].view(*lead)
             return results

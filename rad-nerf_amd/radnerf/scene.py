@@ -121,9 +121,21 @@ class SyntheticScene:
         self.bg_color = torch.ones(1, H * W, 3, dtype=torch.float32, device=self.device)
         self._rays = {}
 
-    def frame(self, i):
-        """Inputs of model.render for frame i (cached rays; everything resident on the device)."""
+    def _lazy_rays(self):
+        return (self.device.type == "cuda" and getattr(self.opt, "engine", "ops") == "fused"
+                and getattr(self.opt, "ray_engine", "fused") == "fused" and getattr(self.opt, "frame_kernels", "merged") == "merged")
+
+    def frame(self, i, lazy_rays=False):
+        """Inputs of model.render for frame i (everything resident on the device).  lazy_rays (fused engine): rays_o / rays_d
+        are two reused buffers and `ray_source` = (pose, intrinsics, W) tells the frame prologue kernel to fill them -- ray
+        generation costs no launch and no cache of per-pose rays is kept."""
         i = i % self.n_frames
+        base = dict(auds=get_audio_features(self.aud_features, self.opt.att, i), bg_coords=self.bg_coords, poses=self.poses6[i:i + 1],
+                    eye=self.eye, index=0, bg_color=self.bg_color)
+        if lazy_rays and self._lazy_rays():
+            if getattr(self, "_ray_bufs", None) is None:
+                self._ray_bufs = (torch.empty(1, self.H * self.W, 3, device=self.device), torch.empty(1, self.H * self.W, 3, device=self.device))
+            return dict(base, rays_o=self._ray_bufs[0], rays_d=self._ray_bufs[1], ray_source=(self.poses[i], self.intrinsics, self.W))
         if i not in self._rays:
             if self.device.type == "cuda" and getattr(self.opt, "engine", "ops") == "fused" and getattr(self.opt, "ray_engine", "fused") == "fused":
                 from . import fused                                   # one kernel (rn_get_rays) instead of ~12 torch launches
@@ -132,19 +144,22 @@ class SyntheticScene:
                 r = get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
             self._rays[i] = (r["rays_o"].contiguous(), r["rays_d"].contiguous())
         rays_o, rays_d = self._rays[i]
-        return dict(rays_o=rays_o, rays_d=rays_d, auds=get_audio_features(self.aud_features, self.opt.att, i),
-                    bg_coords=self.bg_coords, poses=self.poses6[i:i + 1], eye=self.eye, index=0,
-                    bg_color=self.bg_color)
+        return dict(base, rays_o=rays_o, rays_d=rays_d)
 
     def render_kwargs(self):
         o = self.opt
         return dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps, perturb=False, force_all_rays=True, T_thresh=1e-4)
 
-    def render(self, i, want_u8=False):
-        """want_u8: the fused engine's blend kernel also writes the quantised frame (out["image_u8"], SURVEY f-4)."""
-        f = self.frame(i)
+    def render(self, i, want_u8=False, audio_code=None):
+        """want_u8: the fused engine's blend kernel also writes the quantised frame (out["image_u8"], SURVEY f-4).
+        audio_code: (smoothed code, bias block) of this frame when the caller computed them ahead (radnerf/parallel.py)."""
+        f = self.frame(i, lazy_rays=True)
         kw = self.render_kwargs()
         if want_u8:
             kw["want_u8"] = True
+        if "ray_source" in f:
+            kw["ray_source"] = f["ray_source"]
+        if audio_code is not None:
+            kw["audio_code"] = audio_code
         return self.model.render(f["rays_o"], f["rays_d"], f["auds"], f["bg_coords"], f["poses"], eye=f["eye"],
                                  index=f["index"], bg_color=f["bg_color"], **kw)

@@ -437,3 +437,34 @@ def test_frames_are_bit_stable_across_repeats(hiplib, mlp):
             if ref is None:
                 ref = (img, dep)
             assert torch.equal(img, ref[0]) and torch.equal(dep, ref[1])
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f16"])
+def test_merged_frame_kernels_change_no_pixel(hiplib, mlp):
+    """The one-launch prologue (rays from the pose + near/far + initialisation + march of iteration 0), the loop's last
+    compaction doing the check_done bookkeeping, and the torso pass with the blend folded in, against the kernel-per-stage
+    sequence (opt.frame_kernels = "separate"): same image, depth, torso layer, uint8 frame and loop statistics, bit for bit --
+    over three frames, so the live-sample counters the prologue relies on are seen to be left at zero."""
+    a, b = _scene(96, "fused", mlp_dtype=mlp), _scene(96, "fused", mlp_dtype=mlp, frame_kernels="separate")
+    for i in range(3):
+        with torch.no_grad():
+            oa, ob = a.render(i, want_u8=True), b.render(i, want_u8=True)
+        for key in ("image", "torso_alpha", "torso_color", "image_u8"):
+            assert torch.equal(oa[key], ob[key]), (i, key)
+        assert torch.equal(torch.nan_to_num(oa["depth"], nan=-1.0), torch.nan_to_num(ob["depth"], nan=-1.0))
+        assert dict(a.model.last_stats) == dict(b.model.last_stats)
+    from radnerf import fused
+    assert fused.unfinished_frames(a.model) == 0 and fused._state(a.model).state[[6, 14]].tolist() == [0, 0]
+
+
+def test_audio_batches_equal_the_per_frame_audio_path(hiplib):
+    """FrameParallelRenderer(audio_batch=K): codes, smoothing recurrence and bias blocks of K frames in four launches; the
+    frames must be the ones the per-frame path renders (same kernels on the same numbers)."""
+    from radnerf.parallel import FrameParallelRenderer
+    for world, rank in ((1, 0), (3, 1)):
+        a, b = _scene(64, "fused"), _scene(64, "fused")
+        with torch.no_grad():
+            fa = FrameParallelRenderer(a, rank, world, None, gather=False, audio_batch=4)
+            fb = FrameParallelRenderer(b, rank, world, None, gather=False)
+            for s in range(7):                                     # a full batch, then a partial one
+                assert torch.equal(fa.step(s), fb.step(s)), (world, s)
