@@ -56,6 +56,39 @@ def _compile(src, force):
     return obj
 
 
+BINDINGS_SRC = os.path.join(CSRC, "bindings", "radnerf_pybind.cpp")
+BINDINGS_DIR = os.path.join(LIBDIR, "pybind")
+BINDINGS_MODULES = ("_raymarching_face", "_gridencoder", "_shencoder", "_freqencoder")
+
+
+def build_bindings(force=False, verbose=False):
+    """The pybind11 modules with the reference's names (csrc/bindings/radnerf_pybind.cpp): ONE shared object, g++ against
+    torch's headers and libradnerf_hip.so, installed under its four module names in rad-nerf_amd/lib/pybind/ (add that
+    directory to sys.path and the reference's `import _gridencoder as _backend` finds it).  No device code in it."""
+    import shutil
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    os.makedirs(BINDINGS_DIR, exist_ok=True)
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    first = os.path.join(BINDINGS_DIR, BINDINGS_MODULES[0] + suffix)
+    if force or _stale(first, [BINDINGS_SRC, __file__, LIB] + _headers()):
+        tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+               f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+        cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}", "-I/opt/rocm/include", f"-I{INCLUDE}"]
+        cmd += [BINDINGS_SRC, "-o", first, f"-L{tlib}", "-ltorch", "-ltorch_python", "-ltorch_cpu", "-lc10", "-lc10_hip",
+                f"-L{LIBDIR}", "-lradnerf_hip", f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN/.."]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"pybind11 binding failed to build:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}")
+        for name in BINDINGS_MODULES[1:]:           # the same object under the other three module names (it exports every PyInit_)
+            shutil.copyfile(first, os.path.join(BINDINGS_DIR, name + suffix))
+    if verbose:
+        print(f"built {BINDINGS_DIR}/{{{', '.join(BINDINGS_MODULES)}}}{suffix}")
+    return BINDINGS_DIR
+
+
 def build_all(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
@@ -73,3 +106,5 @@ def build_all(force=False, verbose=False):
 
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv, verbose=True)
+    if "--no-bindings" not in sys.argv:
+        build_bindings(force="--force" in sys.argv, verbose=True)

@@ -28,9 +28,47 @@ def test_backend_objects_have_the_pybind_names_and_arities(hiplib):
             assert len(inspect.signature(getattr(obj, fn)).parameters) == arity, (obj_name, fn)
 
 
+def _pybind_modules(hiplib):
+    """The four pybind11 modules (csrc/bindings/radnerf_pybind.cpp), built on demand into rad-nerf_amd/lib/pybind/."""
+    import importlib
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rn_build", os.path.join(root, "rad-nerf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import sysconfig
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    d = mod.BINDINGS_DIR
+    if os.environ.get("RN_REBUILD") == "1" or not all(os.path.exists(os.path.join(d, n + suffix)) for n in mod.BINDINGS_MODULES):
+        d = mod.build_bindings()            # ~2.5 min of g++ on torch's headers; the built objects travel with the tree
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return {name: importlib.import_module(name) for name in mod.BINDINGS_MODULES}
+
+
+def test_pybind_modules_have_the_reference_names_and_arities(hiplib):
+    """Module names of the reference's setup.py / bindings.cpp, every function, and the argument count pybind11 reports."""
+    mods = _pybind_modules(hiplib)
+    for mod_name, key in (("_raymarching_face", "raymarching_backend"), ("_gridencoder", "gridencoder_backend"),
+                          ("_shencoder", "shencoder_backend"), ("_freqencoder", "freqencoder_backend")):
+        have = {n for n in dir(mods[mod_name]) if not n.startswith("_")}
+        assert have == set(REFERENCE_SURFACE[key]), (mod_name, have ^ set(REFERENCE_SURFACE[key]))
+        for fn, arity in REFERENCE_SURFACE[key].items():
+            sig = getattr(mods[mod_name], fn).__doc__.splitlines()[0]
+            assert sig.count("arg") == arity, (mod_name, fn, sig)
+
+
 @pytest.mark.gpu
-def test_reference_style_calls_through_the_backend(po, hiplib, rng):
-    from radnerf_hip.compat_backend import freqencoder_backend, gridencoder_backend, raymarching_backend, shencoder_backend
+@pytest.mark.parametrize("binding", ["ctypes", "pybind11"])
+def test_reference_style_calls_through_the_backend(po, hiplib, rng, binding):
+    if binding == "ctypes":
+        from radnerf_hip.compat_backend import freqencoder_backend, gridencoder_backend, raymarching_backend, shencoder_backend
+    else:
+        mods = _pybind_modules(hiplib)
+        raymarching_backend, gridencoder_backend = mods["_raymarching_face"], mods["_gridencoder"]
+        shencoder_backend, freqencoder_backend = mods["_shencoder"], mods["_freqencoder"]
     from radnerf.scene import ellipsoid_bitfield
     from gridencoder.encoder import level_offsets
     dev = "cuda"
