@@ -44,6 +44,8 @@ def parse():
                          "config[2], one optimisation step of 4096 rays (march_rays_train + network + "
                          "composite_rays_train, backward, Adam)")
     ap.add_argument("--rays", type=int, default=4096, help="rays per training step (--workload train)")
+    ap.add_argument("--train-engine", default="graph", choices=["graph", "eager"],
+                    help="--workload train: replay the steady-state step from a hipGraph (default) or enqueue it launch by launch")
     ap.add_argument("--mlp", default="f32", choices=["f32", "f32x2", "f16"],
                     help="arithmetic of the fused kernel's contractions: f32 = v_mfma_f32_32x32x2_f32 (headline, fp32 parity); "
                          "f32x2 = fp16 hi+lo operand pairs on the f16 matrix cores (fp32-grade); f16 = fp16 operands, fp32 "
@@ -134,19 +136,23 @@ def cpu_baseline(scene_kwargs, size, opt_overrides):
 
 
 def run_train(args):
-    """BASELINE config[2] on one GPU: steps/s and samples/s of Trainer.step (radnerf/train.py) on 4096 random rays of
+    """BASELINE config[2] on one GPU: steps/s and samples/s of the training step (radnerf/train.py) on 4096 random rays of
     frame 0, head model (torso off, as the reference trains the head), perturb on, occupancy grid refreshed every 16
-    steps inside the timed region.  A secondary line: the headline metric stays the render workload."""
+    steps inside the timed region.  --train-engine graph (default): the steady-state step replayed from a hipGraph
+    (GraphedTrainer); eager: one Python-enqueued launch sequence per step.  A secondary line: the headline metric stays the
+    render workload."""
     torch.cuda.set_device(0)
     import radnerf_hip as hip
     from radnerf.scene import SyntheticScene, default_opt
-    from radnerf.train import SyntheticTrainStream, Trainer
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream, Trainer
     size, K, W = args.size, args.steps, args.warmup
     scene = SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine="ops", torso=False, smooth_lips=False, **GRIDS[args.grid]))
     stream = SyntheticTrainStream(scene, n_rays=args.rays)
-    trainer = Trainer(scene.model, scene.opt)
+    graphed = args.train_engine == "graph"
+    trainer = (GraphedTrainer if graphed else Trainer)(scene.model, scene.opt)
     m = scene.model
-    for _ in range(max(W, 17)):          # past the first grid refresh, so mean_count is warm (SURVEY 8(d) config 2)
+    W = max(W, 33)                       # past the first two grid refreshes, so mean_count is warm (SURVEY 8(d) config 2)
+    for _ in range(W):
         trainer.step(stream.batch())
     acc = {}
 
@@ -155,37 +161,63 @@ def run_train(args):
             acc["n"] = acc.get("n", 0.0) + float(a[5])
             return "grid_encode_backward_xyz"
         return None
-    timer = hip.KernelTimer(sel)
-    hip.set_timer(timer)
+    timer = None
+    if not graphed:                      # HIP events around single C-ABI calls only exist on the eager path
+        timer = hip.KernelTimer(sel)
+        hip.set_timer(timer)
     samples = torch.zeros((), dtype=torch.int64, device="cuda")
+    segs = 5
+    seg_ms, losses = [], []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    losses = []
-    for _ in range(K):
+    t_seg = t0
+    for i in range(K):
         losses.append(trainer.step(stream.batch()))
         samples += m.step_counter[(m.local_step - 1) % 16, 0]        # samples marched by this step (stays on the device)
+        if (i + 1) % max(K // segs, 1) == 0 and len(seg_ms) < segs:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            seg_ms.append((now - t_seg) * 1e3 / max(K // segs, 1))
+            t_seg = now
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     hip.set_timer(None)
     samples = int(samples.item())
-    res = timer.results().get("grid_encode_backward_xyz")
+    # cost of one occupancy refresh (update_extra_state: 2.1 M-point density query + dilation + decayed max + mean + packbits)
+    evs = []
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        with torch.no_grad():
+            m.update_extra_state()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    refresh_ms = sorted(a.elapsed_time(b) for a, b in evs)[1]
+    res = timer.results().get("grid_encode_backward_xyz") if timer else None
     roof = None
     if res:
         # scatter-add of 16 levels x 8 corners x 8 B (atomic read-modify-write counted once) + 128 B grad + 12 B coords
         per_launch = acc["n"] / res["launches"] * (1024 + 128 + 12)
         ach = per_launch / (res["avg_ms"] * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="k_grid_bwd_table (xyz grid scatter-add)", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+        roof = dict(bound="hbm", kernel="k_grid_bwd_table_merge (xyz grid scatter-add)", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=ach / HBM_PEAK_GBS, traffic=None, launches=res["launches"], avg_launch_ms=res["avg_ms"],
                     algorithmic_bytes_per_launch=per_launch, share_of_step=res["total_ms"] / (elapsed * 1e3),
-                    note="a training step is launch-latency bound (~65 k samples); no kernel is near a roof")
+                    note="scattered 4-byte float atomics run at the memory side, one 64-B request per touched line: the kernel "
+                         "is bound by the atomic request rate, not by bytes")
+    sps = [1e3 / t for t in seg_ms]
     print(json.dumps({
-        "metric": "training steps/sec @4096 rays", "value": K / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": max(W, 17),
+        "metric": "training steps/sec @4096 rays", "value": K / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"config[2]: single-GPU training step, {args.rays} rays of a {size}x{size} frame, {GRID_TEXT[args.grid]}, "
                                "march_rays_train + network + composite_rays_train fwd/bwd + grid_encode backward + Adam, "
-                               "update_extra_state every 16 steps (inside the timed region)", "grid": args.grid},
+                               "update_extra_state every 16 steps (inside the timed region)", "grid": args.grid,
+                   "train_engine": args.train_engine},
         "samples_per_s": samples / elapsed, "samples_per_step": samples / K,
+        "steps_per_s_by_segment": sps, "spread": (max(sps) - min(sps)) / (sum(sps) / len(sps)) if sps else None,
+        "occupancy_refresh_ms": refresh_ms, "occupancy_refresh_share_of_step": refresh_ms / 16 / (elapsed / K * 1e3),
+        "graph_captures": getattr(trainer, "captures", None), "graph_replays": getattr(trainer, "replays", None),
         "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "roofline": roof}))
 
 

@@ -368,6 +368,34 @@ k_grid_bwd_table(const T *__restrict__ grad, const float *__restrict__ inputs, c
     }
 }
 
+// Wave-level pre-reduction for the LDS merge below: lanes hold (key, v); consecutive lanes with equal keys form a run
+// (ray-ordered samples sit in the same coarse cell for many steps, so on the coarse levels a run is most of a ray).  A
+// segmented inclusive scan sums each run into its last lane, which alone goes on to the LDS table: without it the coarse
+// levels spend their time in same-address LDS atomics (thousands of inserts into a few dozen slots: 600 us per training
+// step on the xyz grid, measured).  Returns true on the lanes that must insert.  Waves with few repeats skip the scan.
+template <uint32_t N_C>
+__device__ __forceinline__ bool merge_runs(uint32_t key, float (&v)[N_C]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    if (__popcll(heads) > 40) return key != ~0u;
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    const uint32_t start = 63u - (uint32_t)__clzll(below);
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        float up[N_C];
+#pragma unroll
+        for (uint32_t c = 0; c < N_C; c++) up[c] = __shfl_up(v[c], off, 64);
+        if (lane >= start + off) {
+#pragma unroll
+            for (uint32_t c = 0; c < N_C; c++) v[c] += up[c];
+        }
+    }
+    const bool tail = lane == 63u || ((heads >> (lane + 1)) & 1ull);
+    return tail && key != ~0u;
+}
+
 // Scatter-add with block-level pre-reduction (C <= 2, D <= 3: one lane per sample and level).  The 256 samples of a
 // block touch 256 * 2^D rows of one level; ray-ordered samples share most of them on the coarse levels, and the
 // corners of neighbouring samples coincide, so the block first sums them in an LDS hash table (open addressing,
@@ -390,46 +418,74 @@ k_grid_bwd_table_merge(const T *__restrict__ grad, const float *__restrict__ inp
     const uint32_t level = blockIdx.y;
     const uint32_t off = (uint32_t)offsets[level];
     float in[D];
-    if (b < B && !load_input<D>(inputs, b, in)) {
+    const bool live = b < B && !load_input<D>(inputs, b < B ? b : 0u, in);       // every lane stays for the wave shuffles
+    {
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
         const float scale = lc.scale[level];
         const uint32_t resolution = lc.resolution[level];
         float pos[D], pos_deriv[D];
         uint32_t pos_grid[D];
-        lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
-        const T *g = (LAYOUT == RN_LAYOUT_LBC) ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
-        T gc[C];
-        load_row<T, C>(g, gc);
+        float g0[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) g0[c] = 0.0f;
+        if (live) {
+            lattice_pos<D>(in, scale, align_corners, interp, pos, pos_deriv, pos_grid);
+            const T *g = (LAYOUT == RN_LAYOUT_LBC) ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
+            T gc[C];
+            load_row<T, C>(g, gc);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) g0[c] = to_f<T>(gc[c]);
+        }
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
             float w = 1;
             uint32_t pgl[D];
+            uint32_t row = ~0u;
+            if (live) {
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                const bool hi = (idx >> d) & 1u;
-                w *= hi ? pos[d] : 1 - pos[d];
-                pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
+                for (uint32_t d = 0; d < D; d++) {
+                    const bool hi = (idx >> d) & 1u;
+                    w *= hi ? pos[d] : 1 - pos[d];
+                    pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
+                }
+                row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
             }
-            const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-            uint32_t slot = (row * 2654435761u) & (kSlots - 1u);
-            while (true) {
-                const uint32_t prev = atomicCAS(&keys[slot], kEmpty, row);
-                if (prev == kEmpty || prev == row) break;
-                slot = (slot + 1u) & (kSlots - 1u);
-            }
+            float v[C];
 #pragma unroll
-            for (uint32_t c = 0; c < C; c++) atomicAdd(&vals[slot * C + c], w * to_f<T>(gc[c]));
+            for (uint32_t c = 0; c < C; c++) v[c] = live ? w * g0[c] : 0.0f;
+            if (merge_runs<C>(row, v)) {
+                uint32_t slot = (row * 2654435761u) & (kSlots - 1u);
+                while (true) {
+                    const uint32_t prev = atomicCAS(&keys[slot], kEmpty, row);
+                    if (prev == kEmpty || prev == row) break;
+                    slot = (slot + 1u) & (kSlots - 1u);
+                }
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) atomicAdd(&vals[slot * C + c], v[c]);
+            }
         }
     }
     __syncthreads();
     T *gg = grad_grid + (size_t)off * C;
-    for (uint32_t i = threadIdx.x; i < kSlots; i += 256) {
-        const uint32_t row = keys[i];
-        if (row != kEmpty) {
-            float v[C];
+    if constexpr (C == 2 && sizeof(T) == 4) {
+        // Two lanes per slot, one channel each: the two float atomics of a row leave in ONE wave-instruction from adjacent
+        // lanes and share their 64-byte request (global float atomics are executed at the memory side, one request per
+        // touched 64 B per instruction: a scattered instruction costs its lane count, MI355X_MICROARCH.md "Global float
+        // atomics") -- half the requests of one-row-per-lane with two instructions.
+        for (uint32_t i = threadIdx.x; i < kSlots * 2u; i += 256) {
+            const uint32_t slot = i >> 1, c = i & 1u;
+            const uint32_t row = keys[slot];
+            if (row != kEmpty) atomicAdd(reinterpret_cast<float *>(gg) + (size_t)row * 2u + c, vals[slot * 2u + c]);
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < kSlots; i += 256) {
+            const uint32_t row = keys[i];
+            if (row != kEmpty) {
+                float v[C];
 #pragma unroll
-            for (uint32_t c = 0; c < C; c++) v[c] = vals[i * C + c];
-            atomic_add_row(gg + (size_t)row * C, v);
+                for (uint32_t c = 0; c < C; c++) v[c] = vals[i * C + c];
+                atomic_add_row(gg + (size_t)row * C, v);
+            }
         }
     }
 }

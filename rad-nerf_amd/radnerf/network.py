@@ -58,6 +58,36 @@ class AudioNet(nn.Module):
         return self.encoder_fc1(x)
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    """y = x W^T for x [M, in] with M >> in, out (the per-sample MLP layers: M ~ 65 k, in / out <= 96).
+
+    Forward and grad_x are ordinary GEMMs.  The weight gradient gy^T x is all reduction and almost no output ([out, in] from a
+    65 k-long contraction): rocBLAS runs it as ONE workgroup walking the whole K (1.6 ms per layer, measured), so it is
+    computed here as a batched product over row chunks -- [S, out, rows] x [S, rows, in] -- followed by a sum over the
+    chunks: every CU gets a slice of the reduction.  Same values up to fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            M = x.shape[0]
+            rows = 2048
+            while rows > 1 and M % rows:
+                rows >>= 1
+            if rows >= 64 and M // rows > 1:
+                gw = torch.bmm(gy.reshape(M // rows, rows, -1).transpose(1, 2), x.reshape(M // rows, rows, -1)).sum(0)
+            else:
+                gw = gy.t() @ x
+        return gx, gw
+
+
 class MLP(nn.Module):
     """Bias-free Linear stack with ReLU between layers (nerf/network.py:69-88)."""
 
@@ -69,8 +99,9 @@ class MLP(nn.Module):
             for l in range(num_layers)])
 
     def forward(self, x):
+        skinny = x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.shape[0] >= 4096 and x.dtype == torch.float32
         for l, layer in enumerate(self.net):
-            x = layer(x)
+            x = _SkinnyLinear.apply(x, layer.weight) if skinny and not torch.is_autocast_enabled() else layer(x)
             if l != self.num_layers - 1:
                 x = F.relu(x, inplace=True)
         return x

@@ -175,7 +175,9 @@ class NeRFRenderer(nn.Module):
 
     def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps):
         """Train branch (renderer.py:206-223): every sample of every ray, packed; one sample counter per step (ring of 16)."""
-        counter = self.step_counter[self.local_step % 16]
+        counter = getattr(self, "_static_counter", None)           # a captured training step counts into a fixed pair
+        if counter is None:
+            counter = self.step_counter[self.local_step % 16]
         counter.zero_()
         self.local_step += 1
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,

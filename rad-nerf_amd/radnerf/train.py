@@ -11,9 +11,14 @@ learning-rate schedule are outside the path (out of scope) and are not
 import torch
 
 
-def make_optimizer(model, lr=5e-3, lr_net=5e-4):
-    """main.py:204; lr for the grid tables, lr_net for the MLPs / audio nets / individual codes."""
-    return torch.optim.Adam(model.get_params(lr, lr_net), betas=(0.9, 0.99), eps=1e-15)
+def make_optimizer(model, lr=5e-3, lr_net=5e-4, fused=None, capturable=False):
+    """main.py:204; lr for the grid tables, lr_net for the MLPs / audio nets / individual codes.  On the GPU the update runs
+    as torch's fused Adam (one kernel per parameter group: the 49 MB table is read and written once per step instead of once
+    per foreach primitive); same arithmetic as the default implementation."""
+    if fused is None:
+        fused = next(model.parameters()).is_cuda
+    return torch.optim.Adam(model.get_params(lr, lr_net), betas=(0.9, 0.99), eps=1e-15, fused=bool(fused),
+                            capturable=bool(capturable))
 
 
 def entropy_of(alphas):
@@ -22,7 +27,7 @@ def entropy_of(alphas):
     return -a * torch.log2(a) - (1 - a) * torch.log2(1 - a)
 
 
-def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1):
+def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1, amb_weight=None):
     """-> (pred_rgb, target_rgb, loss); `data` has the keys of the reference's loader batch
     (nerf/provider.py:588-690): rays_o, rays_d [B,N,3], bg_coords [1,N,2], poses [B,6], face_mask [B,N],
     eye [B,1], auds, index, bg_color [B,N,3], images (head) or bg_torso_color (torso) [B,N,3]."""
@@ -39,7 +44,8 @@ def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1):
         loss = loss + 1e-4 * entropy_of(out["weights_sum"]).mean()
         # ambient coordinates should stay put outside the face (nerf/utils.py:796-803), weight ramped over `iters`
         loss_amb = (out["ambient"] * (~data["face_mask"].view(-1))).mean()
-        loss = loss + min(global_step / iters, 1.0) * lambda_amb * loss_amb
+        # amb_weight: the same factor as a device scalar (a captured step reads it instead of baking the Python float in)
+        loss = loss + (amb_weight if amb_weight is not None else min(global_step / iters, 1.0) * lambda_amb) * loss_amb
     return pred, rgb, loss
 
 
@@ -77,14 +83,14 @@ class Trainer:
     `update_extra_interval` steps as the reference's loop does under --cuda_ray (nerf/utils.py:1015-1018)."""
 
     def __init__(self, model, opt, lr=5e-3, lr_net=5e-4, update_extra_interval=16, iters=200000, lambda_amb=0.1,
-                 prefer_rocblas=True):
+                 prefer_rocblas=True, capturable=False):
         # The weight gradients of the 64-wide MLPs are [64 x ~40 000] x [~40 000 x 96] products: all reduction, almost
         # no output.  On this stack hipBLASLt runs them without a K split (132 us each, measured), rocBLAS in 37 us;
         # eight of them per step make that the largest single item of the step.
         if prefer_rocblas and torch.cuda.is_available() and getattr(torch.version, "hip", None):
             torch.backends.cuda.preferred_blas_library("cublas")      # "cublas" selects rocBLAS on ROCm builds
         self.model, self.opt = model, opt
-        self.optimizer = make_optimizer(model, lr, lr_net)
+        self.optimizer = make_optimizer(model, lr, lr_net, capturable=capturable)
         self.update_extra_interval, self.iters, self.lambda_amb = update_extra_interval, iters, lambda_amb
         self.global_step = 0
 
@@ -100,3 +106,72 @@ class Trainer:
         loss.backward()
         self.optimizer.step()
         return loss.detach()
+
+
+class GraphedTrainer(Trainer):
+    """Trainer.step with the steady-state step replayed from a hipGraph (torch.cuda.CUDAGraph): forward, loss, backward and the
+    fused Adam update are ~320 launches whose enqueue costs the host more than the GPU needs to run them; replaying them as
+    one graph makes the step GPU-bound and its duration repeatable.
+
+    What stays outside the graph: the occupancy refresh every `update_extra_interval` steps (it changes `mean_count`, the
+    marcher's sample budget, i.e. the shapes: the graph is captured again after every refresh, into the same memory pool),
+    the batch (copied into the graph's static input buffers), the ring of per-step sample counters (the captured step
+    counts into one static pair, copied to the ring afterwards) and the first window, whose marcher reads back its sample
+    count (raymarching.py:249-255) and therefore runs eagerly.  Same arithmetic as Trainer.step."""
+
+    def __init__(self, model, opt, **kw):
+        super().__init__(model, opt, capturable=True, **kw)
+        self._graph = self._static = self._loss = self._key = None
+        self._pool = None
+        dev = next(model.parameters()).device
+        self._amb_weight = torch.zeros((), dtype=torch.float32, device=dev)
+        self._counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.captures = self.replays = 0
+
+    def _capture(self, data, key):
+        m = self.model
+        self._graph = self._loss = None                       # release the previous graph before its pool is reused
+        if self._static is None:
+            self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        m._static_counter = self._counter                     # renderer._head_training counts into this pair while captured
+        try:
+            with torch.cuda.graph(g, pool=self._pool):
+                _, _, loss = train_step(m, self._static, self.opt, amb_weight=self._amb_weight)
+                loss.backward()
+                self.optimizer.step()
+        finally:
+            m._static_counter = None
+        m.local_step -= 1                                     # the capture pass went through the Python bookkeeping once
+        self._graph, self._loss, self._key = g, loss, key
+        self.captures += 1
+
+    def step(self, data):
+        m = self.model
+        m.train()
+        if self.update_extra_interval and self.global_step % self.update_extra_interval == 0:
+            with torch.no_grad():
+                m.update_extra_state()
+        self.global_step += 1
+        if m.mean_count <= 0 or not next(m.parameters()).is_cuda:        # first window / CPU: the eager step
+            self.optimizer.zero_grad(set_to_none=True)
+            _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach()
+        key = (int(m.mean_count), tuple(data["rays_o"].shape))
+        if self._graph is None or key != self._key:
+            self._capture(data, key)
+        for k, v in data.items():
+            if torch.is_tensor(v):
+                self._static[k].copy_(v)
+        self._amb_weight.fill_(min(self.global_step / self.iters, 1.0) * self.lambda_amb)
+        self._graph.replay()
+        m.step_counter[m.local_step % 16].copy_(self._counter)
+        m.local_step += 1
+        self.replays += 1
+        return self._loss.detach()

@@ -192,3 +192,28 @@ def test_trainer_refreshes_occupancy_every_interval(hiplib):
     assert torch.isfinite(loss)
     assert m.local_step == 1                    # reset by the refresh before step 5 (renderer.py:499), then one step
     assert m.mean_count > 0 and not torch.equal(before, m.density_bitfield)
+
+
+def test_graphed_trainer_replays_the_step_and_learns(hiplib):
+    """GraphedTrainer: the steady-state step captured in a hipGraph (recaptured after every occupancy refresh) trains like the
+    eager Trainer: loss falls, sample counters and mean_count keep moving, one capture per refresh window."""
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream, train_step
+    scene = _scene(64, torso=False, smooth_lips=False)
+    stream = SyntheticTrainStream(scene, n_rays=2048)
+    m = scene.model
+    with torch.no_grad():
+        m.color_net.net[-1].weight.add_(0.5 * torch.randn_like(m.color_net.net[-1].weight))
+    trainer = GraphedTrainer(m, scene.opt, lr_net=5e-3, update_extra_interval=8)
+    probe = stream.batch()
+
+    def mse():
+        m.train()
+        with torch.no_grad():
+            pred, rgb, _ = train_step(m, probe, scene.opt)
+        return float(((pred - rgb) ** 2).mean())
+    before = mse()
+    losses = [float(trainer.step(stream.batch())) for _ in range(40)]
+    after = mse()
+    assert all(np.isfinite(losses)) and after < 0.5 * before, (before, after)
+    assert trainer.replays >= 30 and 1 <= trainer.captures <= 5
+    assert m.mean_count > 0 and int(m.step_counter[:, 0].max()) > 0
