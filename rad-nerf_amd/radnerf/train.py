@@ -130,9 +130,12 @@ class GraphedTrainer(Trainer):
 
     def _capture(self, data, key):
         m = self.model
-        self._graph = self._loss = None                       # release the previous graph before its pool is reused
+        old = (self._graph, self._loss)        # stays alive until the new graph exists: a pool nobody references is dropped
+        self._loss = None
         if self._static is None:
             self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+            if isinstance(self._static.get("index"), (list, tuple)):     # a Python list would be uploaded inside the capture
+                self._static["index"] = torch.tensor(self._static["index"], dtype=torch.long, device=self._counter.device)
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         torch.cuda.synchronize()
@@ -148,6 +151,7 @@ class GraphedTrainer(Trainer):
             m._static_counter = None
         m.local_step -= 1                                     # the capture pass went through the Python bookkeeping once
         self._graph, self._loss, self._key = g, loss, key
+        del old
         self.captures += 1
 
     def step(self, data):
@@ -169,6 +173,8 @@ class GraphedTrainer(Trainer):
         for k, v in data.items():
             if torch.is_tensor(v):
                 self._static[k].copy_(v)
+            elif k == "index" and isinstance(v, (list, tuple)) and list(v) != self._static[k].tolist():
+                self._static[k].copy_(torch.tensor(v, dtype=torch.long))
         self._amb_weight.fill_(min(self.global_step / self.iters, 1.0) * self.lambda_amb)
         self._graph.replay()
         m.step_counter[m.local_step % 16].copy_(self._counter)

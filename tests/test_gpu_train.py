@@ -203,7 +203,7 @@ def test_graphed_trainer_replays_the_step_and_learns(hiplib):
     m = scene.model
     with torch.no_grad():
         m.color_net.net[-1].weight.add_(0.5 * torch.randn_like(m.color_net.net[-1].weight))
-    trainer = GraphedTrainer(m, scene.opt, lr_net=5e-3, update_extra_interval=8)
+    trainer = GraphedTrainer(m, scene.opt, lr_net=5e-3, update_extra_interval=0)   # keep the ellipsoid occupancy, as the eager test does
     probe = stream.batch()
 
     def mse():
@@ -212,8 +212,11 @@ def test_graphed_trainer_replays_the_step_and_learns(hiplib):
             pred, rgb, _ = train_step(m, probe, scene.opt)
         return float(((pred - rgb) ** 2).mean())
     before = mse()
-    losses = [float(trainer.step(stream.batch())) for _ in range(40)]
+    losses = [float(trainer.step(stream.batch())) for _ in range(4)]          # no sample budget yet: eager steps
+    assert trainer.captures == 0
+    m.mean_count = int(m.step_counter[:4, 0].float().mean().item() * 1.2)     # what update_extra_state would derive (+ margin)
+    losses += [float(trainer.step(stream.batch())) for _ in range(36)]
     after = mse()
     assert all(np.isfinite(losses)) and after < 0.5 * before, (before, after)
-    assert trainer.replays >= 30 and 1 <= trainer.captures <= 5
-    assert m.mean_count > 0 and int(m.step_counter[:, 0].max()) > 0
+    assert trainer.replays == 36 and trainer.captures == 1
+    assert int(m.step_counter[:, 0].max()) > 0 and m.local_step == 4 + 36 + 2   # +2: the two probes
