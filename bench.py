@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=250)     # 20 warm-up + 250 timed frames (10 s of the 25 FPS stream)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--engine", default=os.environ.get("RN_ENGINE", "auto"), choices=["auto", "ops", "fused"])
     ap.add_argument("--grid", default="hash19", choices=sorted(GRIDS),
@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--audio-batch", type=int, default=8,
                     help="frames whose audio codes / smoothing recurrence / bias blocks are computed together from the resident "
                          "feature stream (4 launches per batch instead of 4 per frame; 0 = per frame, as a live stream would)")
+    ap.add_argument("--latency-every", type=int, default=8,
+                    help="bracket every n-th timed frame with HIP events on the render stream: mean / p50 / p95 frame latency "
+                         "(SURVEY 8(d); the GUI of the reference times a frame the same way, nerf/gui.py:174-202)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -127,12 +130,37 @@ def cpu_baseline(scene_kwargs, size, opt_overrides):
         _, _, stats = po.render_frame(*args)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 20:
+        if dt > 6.0 or reps >= 12:
             break
     return dict(value=reps / dt, unit="frames/s", cores=po.num_threads(), kind="port",
                 sample=f"{reps} x frame 0 of the same {size}x{size} workload through oracle/ (orc_render_frame, "
                        f"fp32, OpenMP), {stats['live_samples']} samples/frame",
                 samples_per_s=stats["live_samples"] * reps / dt)
+
+
+def cpu_reference_flow(size, opt_overrides, budget_s, label):
+    """SURVEY 8(d)'s CPU baseline: the reference's control flow (this tree's mirror of nerf/network.py + nerf/renderer.py,
+    "ops" loop shape -- the reference's own files do not travel to this box) over CPU restatements of the kernels (oracle,
+    OpenMP) and PyTorch CPU GEMMs for the MLPs, fp32, autocast off, all host cores (oracle/cpu_ops.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_ops
+    import pyoracle as po
+    from radnerf.scene import SyntheticScene, default_opt
+    cores = po.num_threads()
+    torch.set_num_threads(cores)
+    scene = SyntheticScene(H=size, W=size, n_frames=8, device="cpu", opt=default_opt(**opt_overrides))
+    with cpu_ops.cpu_operators(scene.model), torch.no_grad():
+        scene.render(0)                         # warm-up frame
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            scene.render(1 + reps)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or reps >= 10:
+                break
+    return dict(value=reps / dt, unit="frames/s", cores=cores, kind="reference-flow", workload=label,
+                sample=f"{reps} frame(s) of {size}x{size} after 1 warm-up: mirror of the reference's Python loop over oracle CPU operators "
+                       f"+ torch CPU GEMMs ({torch.get_num_threads()} threads)")
 
 
 def run_train(args):
@@ -284,10 +312,19 @@ def main():
             t0 = time.perf_counter()
             short = 0
             try:
+                lat_events = []
+                le = max(args.latency_every, 1)
                 for s in range(W, W + K):
                     if engine == "fused":
                         hip.prof_pause((s - W) % max(args.time_every, 1) != 0)
-                    fpr.step(s)
+                    if (s - W) % le == le // 2:     # never a frame whose kernel dispatches carry timing events
+                        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ea.record()
+                        fpr.step(s)
+                        eb.record()
+                        lat_events.append((ea, eb))
+                    else:
+                        fpr.step(s)
                 fpr.finish()
             except LoopHintTooSmall:        # the device flagged a frame: this timing is void, repeat with every iteration
                 short = 1
@@ -327,6 +364,12 @@ def main():
     if rank == 0:
         res = timer.results()
         roof = None
+        lat = sorted(a.elapsed_time(b) for a, b in lat_events)
+        latency = None
+        if lat:
+            latency = dict(mean=sum(lat) / len(lat), p50=lat[len(lat) // 2], p95=lat[min(len(lat) - 1, int(0.95 * len(lat)))],
+                           frames_sampled=len(lat), method="HIP events on the render stream around every "
+                           f"{max(args.latency_every, 1)}-th timed frame (frames are enqueued back to back, so this is the GPU time of a frame)")
         if engine == "fused" and fused_launches:
             # the kernel was timed on every --time-every-th step; the stream's frames hold the same number of samples to within
             # a fraction of a percent, so the timed steps' share of the counted samples is their share of the steps
@@ -342,6 +385,8 @@ def main():
             # the gathers bind.  `bound` names the binding roof, the other view rides along.
             tkey = {"f32": "nerf_fused", "f16": "nerf_fused_h16", "f32x2": "nerf_fused_x2"}[args.mlp]
             common = dict(traffic=fpr.measured_traffic(tkey),
+                          traffic_source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile "
+                                         "run of this command (static in this line, not measured in this run)",
                           launches=fused_launches, avg_launch_ms=fused_ms / fused_launches,
                           share_of_step=fused_ms / (elapsed * 1e3 * timed_frac), launches_with_work=iters_timed,
                           avg_launch_ms_with_work=sum(fused_durs[:iters_timed]) / max(iters_timed, 1),
@@ -386,17 +431,28 @@ def main():
                                    "max 16 steps/ray, 25 FPS pose stream, torso pass on"
                                    + (", regime A (opaque: sigma ~ 20..300 inside the head, rays terminate on T < 1e-4)" if args.regime == "A" else ""),
                        "grid": args.grid, "engine": engine, "frames_per_gpu": K,
+                       "scene": {"occupancy_ellipsoid_semi_axes": [0.40, 0.42, 0.40], "camera": "OrbitCamera radius 3.35, fovy 21.24 deg, "
+                                 "yaw 8 deg sin(2 pi t / 4 s), pitch 4 deg sin(2 pi t / 2.5 s)", "regime": args.regime,
+                                 "note": "SURVEY 8(d) proposes semi-axes (0.33, 0.42, 0.33); (0.40, 0.42, 0.40) reproduces the published "
+                                         "trace's 31 % of rays hitting the head at this pose"},
+                       "audio_batch": args.audio_batch if engine == "fused" and not tile else 0,
                        "loop_iterations_enqueued": (getattr(getattr(scene.model, "_fused_state", None), "loop_hint", None)
                                                     or scene.opt.max_steps),
                        "parallelism": f"{'tile' if tile else 'frame'}-parallel x{world}"},
             # tile-parallel: rank 0 counts its own band's samples; the bands are interleaved, so x world is the frame's
             "samples_per_s": live_pf * (world if tile else 1) * fps, "samples_per_frame": live_pf * (world if tile else 1),
             "sample_slots_per_frame": slots_pf * (world if tile else 1),
+            "frame_latency_ms": latency,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline and args.regime == "B":
             cb_size = args.cpu_baseline_size or size
             out["cpu_baseline"] = cpu_baseline({}, cb_size, GRIDS[args.grid])
+            if not tile:
+                # the reference-flow baseline on config[0] (one 256 x 256 frame, shipped tiled grids) and config[1]
+                out["cpu_baseline_reference_flow"] = [
+                    cpu_reference_flow(256, GRIDS["tiled16"], 4.0, "config[0]: 256x256, shipped tiled T=2^16 grids"),
+                    cpu_reference_flow(cb_size, GRIDS[args.grid], 10.0, f"config[1]: {cb_size}x{cb_size}, {GRID_TEXT[args.grid]}")]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
