@@ -436,6 +436,10 @@ def main():
                                  "note": "SURVEY 8(d) proposes semi-axes (0.33, 0.42, 0.33); (0.40, 0.42, 0.40) reproduces the published "
                                          "trace's 31 % of rays hitting the head at this pose"},
                        "audio_batch": args.audio_batch if engine == "fused" and not tile else 0,
+                       "collectives": ({"per_frame": 1, "kind": "all_gather of uint8 band rows (+ 68 B of loop counts that verify the band-local "
+                                        "step schedules)", "schedule": getattr(fpr, "schedule", None), "frames_redone_exactly": getattr(fpr, "redone", 0)}
+                                       if tile else {"per_frame": 1.0 / max(getattr(fpr, "gather_every", 1), 1), "kind": "gather of uint8 frames to rank 0, "
+                                                     f"{getattr(fpr, 'gather_every', 1)} frames per collective"}) if world > 1 else None,
                        "loop_iterations_enqueued": (getattr(getattr(scene.model, "_fused_state", None), "loop_hint", None)
                                                     or scene.opt.max_steps),
                        "parallelism": f"{'tile' if tile else 'frame'}-parallel x{world}"},

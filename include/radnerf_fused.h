@@ -89,7 +89,7 @@ int rn_nerf_fused_forward(const float *xyzs, const float *dirs, const float *del
                           float *ambient, int mlp_dtype, rn_stream_t stream);
 
 /* ---- device-side inference loop ------------------------------------------------------------------ */
-#define RN_HEAD_STATE_INTS 32 /* int32 words of loop state the caller provides (zeroing not required) */
+#define RN_HEAD_STATE_INTS 64 /* int32 words of loop state the caller provides (zeroed once before first use) */
 
 typedef struct {
     /* inputs */
@@ -166,6 +166,9 @@ int rn_head_reschedule(const rn_head_t *h, uint32_t iter_done, uint32_t schedule
 #define RN_HEAD_ST_LIVE 17       /* live samples evaluated */
 #define RN_HEAD_ST_SLOTS 18      /* sample slots n_alive * n_step summed over iterations */
 #define RN_HEAD_ST_UNFINISHED 19 /* frames whose loop was still active when rn_head_check_done looked (see below) */
+#define RN_HEAD_ST_HIST 32       /* state[32 + i], i = 0 .. max_steps (<= 31): live rays entering loop iteration i of the frame in
+                                    flight (0 once the loop is over).  A shard of a frame publishes these so the ranks can verify,
+                                    after the fact, that their band-local step schedules were the whole frame's (radnerf/parallel.py) */
 /* Speculative loop length.  A caller that knows how many iterations frames of this stream need (device counters of
  * earlier frames) may enqueue fewer than max_steps iterations and skip the no-op launches behind them; this entry point
  * then records, on the device, whether the loop really was over after iteration iters_done - 1: if it was not,

@@ -490,6 +490,7 @@ k_head_begin(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
         next_state(state, N, N, 0, max_steps);
         state[6] = 0;
         for (int i = 8; i < 16; i++) state[i] = 0;  // statistics words [16..] accumulate across frames (caller-owned)
+        state[RN_HEAD_ST_HIST] = (int32_t)N;
     }
     if (n >= N) return;
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
@@ -581,6 +582,7 @@ k_frame_begin(RaySource rs, float *__restrict__ rays_o, float *__restrict__ rays
     if (n == 0) {
         next_state(state, N, N, 0, max_steps);
         for (int i = 8; i < 16; i++) state[i] = 0;
+        state[RN_HEAD_ST_HIST] = (int32_t)N;
         atomicAdd(&state[RN_HEAD_ST_ITERS], 1);
         atomicAdd(&state[RN_HEAD_ST_SLOTS], (int32_t)N);          // n_alive * n_step = N * 1
     }
@@ -719,7 +721,7 @@ __global__ void __launch_bounds__(kLoopBlock)
 k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps,
                const int32_t *__restrict__ rays_in, int32_t *__restrict__ rays_out,
                const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats,
-               MarchArgs m, uint32_t close_frame) {
+               MarchArgs m, uint32_t close_frame, uint32_t iter) {
     __shared__ uint32_t red[kLoopBlock / kWave];
     __shared__ uint32_t red_live[kLoopBlock / kWave];
     __shared__ uint32_t red_all[kLoopBlock / kWave];
@@ -729,6 +731,7 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
         // close_frame (last compaction of a frame's loop): both live-sample counters back to zero for the next frame's
         // prologue; the loop is over, so rn_head_check_done has nothing to flag
         if (close_frame && blockIdx.x == 0 && threadIdx.x == 0) { stats[6] = 0; stats[8 + 6] = 0; }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && iter + 1 < 32) stats[RN_HEAD_ST_HIST + iter + 1] = 0;
         return;
     }
     const uint32_t n_alive = (uint32_t)st[0];
@@ -771,6 +774,7 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
     const bool active_next = step_next < max_steps && n_next > 0;
     if (last && threadIdx.x == 0) {
         next_state(st_next, N, n_next, step_next, max_steps);
+        if (iter + 1 < 32) stats[RN_HEAD_ST_HIST + iter + 1] = active_next ? (int32_t)n_next : 0;   // live rays entering iteration iter + 1
         uint32_t sum = 0;
         for (int w = 0; w < kLoopBlock / kWave; w++) sum += red_live[w];
         if (sum) atomicAdd(&stats[RN_HEAD_ST_LIVE], (int32_t)sum);
@@ -1333,10 +1337,10 @@ int rn_head_iterate_ex(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_g
                           h->xyzs, h->dirs, h->deltas, block_live[(it + 1) & 1u], h->live_slots};
         if (it + 1 < first_iter + n_iters)
             hipLaunchKernelGGL(k_head_compact<true>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
-                               h->block_counts, block_live[it & 1u], h->state, m, 0u);
+                               h->block_counts, block_live[it & 1u], h->state, m, 0u, it);
         else
             hipLaunchKernelGGL(k_head_compact<false>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
-                               h->block_counts, block_live[it & 1u], h->state, m, (flags & RN_LOOP_CLOSE_FRAME) ? 1u : 0u);
+                               h->block_counts, block_live[it & 1u], h->state, m, (flags & RN_LOOP_CLOSE_FRAME) ? 1u : 0u, it);
     }
     return check_launch("head_iterate");
 }

@@ -49,7 +49,8 @@ class HeadT(C.Structure):
                 ("block_counts", _ptr), ("live_slots", _ptr), ("order_w", _u32)]
 
 
-RN_HEAD_STATE_INTS = 32
+RN_HEAD_STATE_INTS = 64
+ST_HIST = 32
 ST_UNFINISHED = 19
 ST_ACTIVE, ST_ITERS, ST_LIVE, ST_SLOTS = 4, 16, 17, 18
 
@@ -277,6 +278,13 @@ def loop_counters(model):
     if st is None or st._N == 0:
         return None
     return st.state[ST_ITERS:ST_SLOTS + 1].cpu().tolist()
+
+
+def loop_history(model, n):
+    """Device view of the live-ray count entering each of the first n loop iterations of the frame just enqueued (0 once the
+    loop is over); see RN_HEAD_ST_HIST."""
+    st = _state(model)
+    return st.state[ST_HIST:ST_HIST + n]
 
 
 def unfinished_frames(model):

@@ -16,9 +16,15 @@ centre of the image, so contiguous bands would leave the outer ranks idle).  Eve
 pixels and the only bulk exchange is the gather of finished uint8 rows; every rank advances the audio EMA itself.
 One scalar is shared: the reference's step policy n_step = max(min(N // n_alive, 8), 1) (renderer.py:249) looks at
 the live-ray count of the whole call, and because `step += n_step` can overshoot max_steps the schedule shows in
-the pixels.  With schedule="frame" (default) the ranks therefore sum their live counts between loop iterations
-(a 4-byte all-reduce enqueued on the device, no host read-back), which makes the assembled frame equal to a
-single-GPU render of the whole image; schedule="band" skips it.
+the pixels.  Interleaved bands are statistically alike, so a band's own policy (N_band // alive_band) almost always
+picks the whole frame's n_step -- but not provably.  schedule="verify" (default with the fused engine) therefore lets
+every rank follow its band's policy with NO collective inside the loop, appends the 17 live-ray counts the loop went
+through to the rows it sends into the frame's gather (68 bytes), and checks on every rank, when the gather is
+consumed, that the band-local schedules were the whole frame's; a frame for which they were not (rare) is rendered
+again with schedule="frame" semantics -- the ranks sum their live counts between loop iterations (a 4-byte
+all-reduce enqueued on the device, no host read-back).  Either way the assembled frame equals a single-GPU render of
+the whole image and the common case costs ONE collective per frame, the gather.  schedule="frame" always takes the
+exact path; schedule="band" never checks.
 """
 import json
 import os
@@ -103,13 +109,19 @@ class LoopHintTooSmall(RuntimeError):
 
 
 class FrameParallelRenderer(_Bookkeeping):
-    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False, gather_every=8, audio_batch=0):
+    def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False, gather_every=8, audio_batch=0,
+                 gather_to="rank0"):
         """speculate_loop (fused engine): after the first finish() the renderer knows how many loop iterations the
         stream's frames take (device counters) and enqueues that many + 2 per frame instead of max_steps, skipping
         the no-op launches behind them; the device flags any frame for which that was not enough and finish() raises
         LoopHintTooSmall so the caller can render the batch again (never observed on a continuous pose stream)."""
         self.scene, self.rank, self.world, self.dist = scene, rank, world, dist
         self.gather = gather and dist is not None and world > 1
+        # gather_to="rank0" (default): finished frames go to rank 0 only (the process that encodes / shows the video): 1/world of
+        # the bytes an all_gather moves over the xGMI links; "all": every rank receives every frame.
+        if gather_to not in ("rank0", "all"):
+            raise ValueError("gather_to must be 'rank0' or 'all'")
+        self.gather_to = gather_to
         # Finished frames leave in batches of `gather_every` (one collective per batch: a frame takes ~1 ms, and a collective
         # per millisecond would keep an RCCL kernel waiting for CUs that the persistent network kernels occupy entirely).
         # finish() flushes a partial batch, so every rank issues the same sequence of collectives.
@@ -203,33 +215,60 @@ class FrameParallelRenderer(_Bookkeeping):
             return
         frames = torch.stack(self._batch, 0)
         self._batch = []
-        if self.dist.get_backend() == "nccl":
-            # async: RCCL runs the gather on its own stream, overlapping the next frames' kernels
-            buf = torch.empty((self.world,) + tuple(frames.shape), dtype=torch.uint8, device=frames.device)
-            work = self.dist.all_gather_into_tensor(buf, frames, async_op=True)
-        else:  # gloo gathers host tensors (CPU tests, multi-rank rehearsals on a one-GPU box)
-            frames = frames.cpu()
-            buf = torch.empty((self.world,) + tuple(frames.shape), dtype=torch.uint8)
-            work = self.dist.all_gather(list(buf.unbind(0)), frames, async_op=True)
+        nccl = self.dist.get_backend() == "nccl"
+        if not nccl:
+            frames = frames.cpu()          # gloo moves host tensors (CPU tests, multi-rank rehearsals on a one-GPU box)
+        shape = (self.world,) + tuple(frames.shape)
+        if self.gather_to == "rank0":
+            buf = torch.empty(shape, dtype=torch.uint8, device=frames.device) if self.rank == 0 else None
+            work = self.dist.gather(frames, list(buf.unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
+        else:
+            buf = torch.empty(shape, dtype=torch.uint8, device=frames.device)
+            if nccl:                       # async: RCCL runs the collective on its own stream, overlapping the next frames' kernels
+                work = self.dist.all_gather_into_tensor(buf, frames, async_op=True)
+            else:
+                work = self.dist.all_gather(list(buf.unbind(0)), frames, async_op=True)
         self.pending.append((work, buf, frames))
 
     def _render_for_count(self, step):
         self.scene.render(frame_of(step, self.rank, self.world))
 
     def finish(self):
-        """Wait for every outstanding gather; returns the gathered [world, H, W, 3] uint8 stacks in step order."""
+        """Wait for every outstanding gather; returns the gathered [world, H, W, 3] uint8 stacks in step order (on rank 0
+        only when gather_to == "rank0": the other ranks get an empty list)."""
         if self.gather:
             self._flush()
         done = []
         for work, buf, _ in self.pending:
             work.wait()
-            done.extend(buf[:, i] for i in range(buf.shape[1]))   # per step: [world, H, W, 3]
+            if buf is not None:
+                done.extend(buf[:, i] for i in range(buf.shape[1]))   # per step: [world, H, W, 3]
         if done:
             self.frames_u8 = done[-1]
         self.pending = []
         if self.speculate_loop:
             self._update_loop_hint()
         return done
+
+
+def band_schedule_is_frame_schedule(n_rays, histories, max_steps):
+    """Did ranks that each followed n_step = max(min(N_r // alive_r, 8), 1) for their own band walk the whole frame's
+    schedule max(min(sum N_r // sum alive_r, 8), 1)?  histories[r][i] = live rays of rank r entering loop iteration i (0
+    once its loop is over).  Checked iteration by iteration: while every earlier iteration agreed the counts ARE the whole
+    frame's, so their sums are what a single-GPU render would have seen."""
+    total_n = sum(n_rays)
+    step = 0
+    for i in range(len(histories[0])):
+        alive = [int(h[i]) for h in histories]
+        total = sum(alive)
+        if total == 0 or step >= max_steps:
+            return True
+        want = max(min(total_n // total, 8), 1)
+        for n_r, a in zip(n_rays, alive):
+            if a > 0 and max(min(n_r // a, 8), 1) != want:
+                return False
+        step += want
+    return True
 
 
 def stripe_rows(H, rank, world, band=8):
@@ -243,19 +282,21 @@ class TileParallelRenderer(_Bookkeeping):
     and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (identical on every rank)."""
 
     def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule=None, speculate_loop=False):
-        """schedule="frame": the ranks agree on the whole frame's step schedule (one 4-byte all-reduce per loop
-        iteration, enqueued on the device; fused engine only) so the assembled image IS the whole-frame render;
-        schedule="band": no collective inside the loop, each band follows the reference's policy for its own rays.
-        Default: "frame" with the fused engine, "band" otherwise."""
+        """schedule="verify" (default with the fused engine): band-local step policy, no collective inside the loop, the
+        schedule checked from counts that ride in the frame's gather, the rare mismatching frame rendered again exactly;
+        "frame": every frame with the whole frame's schedule (one 4-byte all-reduce per loop iteration, enqueued on the
+        device); "band": band-local policy, never checked (each band is then the reference applied to that band's rays).
+        Default without the fused engine: "band"."""
         self.scene, self.rank, self.world, self.dist, self.band = scene, rank, world, dist, band
         fused_engine = getattr(getattr(scene, "opt", None), "engine", "ops") == "fused"
         if schedule is None:
-            schedule = "frame" if fused_engine else "band"
+            schedule = "verify" if fused_engine else "band"
+        if schedule in ("frame", "verify") and dist is not None and world > 1 and not fused_engine:
+            raise RuntimeError(f"schedule='{schedule}' needs the fused engine (device-resident loop state)")
         if schedule == "frame" and dist is not None and world > 1:
-            if not fused_engine:
-                raise RuntimeError("schedule='frame' needs the fused engine (device-resident loop state)")
             scene.model.shard_schedule = (dist, scene.H * scene.W)
         self.schedule = schedule
+        self.redone = 0                                            # frames rendered again because the band schedules disagreed
         self.speculate_loop = speculate_loop and fused_engine      # as in FrameParallelRenderer
         self._frames_since_finish = 0
         self._counters = None
@@ -278,53 +319,99 @@ class TileParallelRenderer(_Bookkeeping):
             self._rays[key] = (f["rays_o"][:, px].contiguous(), f["rays_d"][:, px].contiguous())
         return f, self._rays[key], self._static
 
-    def render_local(self, i):
+    def render_local(self, i, audio_code=None):
         """This rank's pixels of frame i through the scene's model: [n_rows, W, 3] uint8."""
         sc = self.scene
         f, (rays_o, rays_d), (bg_coords, bg_color) = self._inputs(i)
+        kw = dict(sc.render_kwargs())
+        if audio_code is not None:
+            kw["audio_code"] = audio_code
         out = sc.model.render(rays_o, rays_d, f["auds"], bg_coords, f["poses"], eye=f["eye"], index=f["index"],
-                              bg_color=bg_color, **sc.render_kwargs())
+                              bg_color=bg_color, **kw)
         return (out["image"].reshape(-1, sc.W, 3) * 255).to(torch.uint8)
 
     def _render_for_count(self, step):
         self.render_local(step)
 
+    _HIST = 17          # live-ray counts entering iterations 0 .. 16 (max_steps = 16 in every BASELINE config)
+
+    def _gather(self, payload):
+        """One collective: every rank's payload (uint8, same length) to every rank.  Returns (work, buf [world, len])."""
+        nccl = self.dist.get_backend() == "nccl"
+        if not nccl:
+            payload = payload.cpu()                      # gloo gathers host tensors (CPU tests, 1-GPU rehearsals)
+        buf = torch.empty((self.world, payload.numel()), dtype=torch.uint8, device=payload.device)
+        if nccl:
+            work = self.dist.all_gather_into_tensor(buf, payload.contiguous(), async_op=True)
+        else:
+            work = self.dist.all_gather(list(buf.unbind(0)), payload.contiguous(), async_op=True)
+        return work, buf, payload
+
+    def _payload(self, u8, verify):
+        rows = u8
+        if u8.shape[0] < self.n_max:                     # ragged last band: pad so one fixed-size gather does it
+            rows = torch.cat([u8, u8.new_zeros((self.n_max - u8.shape[0],) + tuple(u8.shape[1:]))])
+        parts = [rows.reshape(-1)]
+        if verify:
+            from . import fused
+            parts.append(fused.loop_history(self.scene.model, self._HIST).clone().view(torch.uint8))
+        return torch.cat(parts) if len(parts) > 1 else parts[0]
+
     def step(self, i):
         u8 = self.render_local(i)
         self._frames_since_finish += 1
         if self.dist is None or self.world == 1:
-            self.pending.append((None, None, u8))
+            self.pending.append(dict(frame=i, work=None, buf=None, keep=u8))
             return u8
-        send = u8
-        if u8.shape[0] < self.n_max:                     # ragged last band: pad so one fixed-size gather does it
-            send = torch.cat([u8, u8.new_zeros((self.n_max - u8.shape[0],) + tuple(u8.shape[1:]))])
-        nccl = self.dist.get_backend() == "nccl"
-        if not nccl:
-            send = send.cpu()                            # gloo gathers host tensors (CPU tests, 1-GPU rehearsals)
-        buf = torch.empty((self.world,) + tuple(send.shape), dtype=torch.uint8, device=send.device)
-        if nccl:
-            work = self.dist.all_gather_into_tensor(buf, send.contiguous(), async_op=True)
-        else:
-            work = self.dist.all_gather(list(buf.unbind(0)), send.contiguous(), async_op=True)
-        self.pending.append((work, buf, send))
+        verify = self.schedule == "verify"
+        work, buf, sent = self._gather(self._payload(u8, verify))
+        enc_a = getattr(self.scene.model, "enc_a", None)
+        self.pending.append(dict(frame=i, work=work, buf=buf, keep=sent, verify=verify,
+                                 enc_a=enc_a.clone() if (verify and torch.is_tensor(enc_a)) else None))
         return u8
 
-    def assemble(self, buf):
+    def _rows_of(self, buf):
+        n = self.n_max * self.scene.W * 3
+        return buf[:, :n].reshape(self.world, self.n_max, self.scene.W, 3)
+
+    def assemble(self, rows):
         sc = self.scene
-        frame = torch.empty((sc.H, sc.W, 3), dtype=torch.uint8, device=buf.device)
+        frame = torch.empty((sc.H, sc.W, 3), dtype=torch.uint8, device=rows.device)
         for r in range(self.world):
-            rows = self.rows[r].to(buf.device)
-            frame[rows] = buf[r, :len(rows)]
+            own = self.rows[r].to(rows.device)
+            frame[own] = rows[r, :len(own)]
         return frame
+
+    def _redo_exact(self, p):
+        """Frame p["frame"] again with the whole frame's schedule (per-iteration all-reduce), with the audio code it had."""
+        m = self.scene.model
+        m.shard_schedule = (self.dist, self.scene.H * self.scene.W)
+        try:
+            u8 = self.render_local(p["frame"], audio_code=(p["enc_a"], None) if p["enc_a"] is not None else None)
+            work, buf, _ = self._gather(self._payload(u8, False))
+            work.wait()
+        finally:
+            m.shard_schedule = None
+        self.redone += 1
+        return self.assemble(self._rows_of(buf))
 
     def finish(self):
         frames = []
-        for work, buf, u8 in self.pending:
-            if work is None:
-                frames.append(self.assemble(u8[None]))
-            else:
-                work.wait()
-                frames.append(self.assemble(buf))
+        max_steps = int(getattr(getattr(self.scene, "opt", None), "max_steps", 16))
+        for p in self.pending:
+            if p["work"] is None:
+                frames.append(self.assemble(p["keep"][None]))
+                continue
+            p["work"].wait()
+            buf = p["buf"]
+            if p.get("verify"):
+                n = self.n_max * self.scene.W * 3
+                hist = buf[:, n:n + 4 * self._HIST].cpu().contiguous().view(torch.int32).reshape(self.world, self._HIST).tolist()
+                n_rays = [len(r) * self.scene.W for r in self.rows]
+                if not band_schedule_is_frame_schedule(n_rays, hist, max_steps):
+                    frames.append(self._redo_exact(p))           # every rank reaches the same verdict from the same bytes
+                    continue
+            frames.append(self.assemble(self._rows_of(buf)))
         self.pending = []
         if self.speculate_loop:
             self._update_loop_hint()

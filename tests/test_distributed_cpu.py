@@ -67,7 +67,7 @@ def _sequential(n_total, n_frames):
     return frames, encs
 
 
-def _worker(rank, world, port, steps, n_frames, ret, gather_every=8):
+def _worker(rank, world, port, steps, n_frames, ret, gather_every=8, gather_to="all"):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -75,7 +75,7 @@ def _worker(rank, world, port, steps, n_frames, ret, gather_every=8):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from radnerf.parallel import FrameParallelRenderer, frame_of
     scene = _StandInScene(n_frames)
-    fpr = FrameParallelRenderer(scene, rank, world, dist, gather_every=gather_every)
+    fpr = FrameParallelRenderer(scene, rank, world, dist, gather_every=gather_every, gather_to=gather_to)
     for s in range(steps):
         fpr.step(s)
     stacks = fpr.finish()
@@ -106,6 +106,19 @@ def test_frame_parallel_equals_sequential(hiplib, world, steps, gather_every):
         for s in range(steps):
             g = s * world + rank
             np.testing.assert_allclose(rendered[g], seq_encs[g].numpy(), rtol=0, atol=1e-7)
+
+
+def test_frame_parallel_gather_to_rank0(hiplib):
+    """Default collective of the frame-parallel renderer: finished frames go to rank 0 only (world 4, partial last batch)."""
+    world, steps, n_frames = 4, 5, 32
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), steps, n_frames, ret, 2, "rank0"), nprocs=world, join=True)
+    seq_frames, _ = _sequential(steps * world, n_frames)
+    assert len(ret[0]["stacks"]) == steps and all(len(ret[r]["stacks"]) == 0 for r in range(1, world))
+    for s in range(steps):
+        for q in range(world):
+            assert np.array_equal(ret[0]["stacks"][s][q], seq_frames[s * world + q].numpy()), (s, q)
 
 
 def test_skipped_frames_partition():
@@ -164,7 +177,7 @@ def _tile_worker(rank, world, port, Hh, Ww, band, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,Hh,band", [(2, 16, 4), (3, 20, 4), (2, 10, 8)])   # even split, ragged split, short last band
+@pytest.mark.parametrize("world,Hh,band", [(2, 16, 4), (3, 20, 4), (2, 10, 8), (8, 128, 8)])   # even / ragged split, short last band, config 4's world of 8
 def test_tile_parallel_equals_whole_frame(hiplib, world, Hh, band):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
@@ -182,3 +195,17 @@ def test_tile_parallel_equals_whole_frame(hiplib, world, Hh, band):
     for rank in range(world):
         for i in range(2):
             assert np.array_equal(ret[rank][i], expect[i]), (rank, i)
+
+
+def test_band_schedules_are_checked_against_the_whole_frame_schedule():
+    """The host-side verdict of TileParallelRenderer(schedule="verify"): per-iteration live-ray counts of every rank (they ride in
+    the frame's gather) -> did band-local policies n_step = max(min(N_r // alive_r, 8), 1) equal the whole frame's?"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
+    from radnerf.parallel import band_schedule_is_frame_schedule as ok
+    N = [1000, 1000]
+    assert ok(N, [[1000, 300, 280, 0], [1000, 310, 290, 0]], 16)                    # 2000 // 610 = 3 = 1000 // 300 = 1000 // 310
+    assert not ok(N, [[1000, 250, 0, 0], [1000, 340, 0, 0]], 16)                    # rank 0: 4, rank 1: 2, frame: 2000 // 590 = 3
+    assert ok(N, [[1000, 0, 0, 0], [1000, 400, 390, 0]], 16) is False               # frame: 2000 // 400 = 5, rank 1: 1000 // 400 = 2
+    assert ok([1000, 500], [[1000, 400, 0], [500, 200, 0]], 16)                     # ragged bands, same ratio
+    assert ok(N, [[1000, 300, 290, 280], [1000, 300, 290, 280]], 4)                 # step reaches max_steps = 4 after 1 + 3: later counts ignored

@@ -46,9 +46,11 @@ def test_bands_match_oracle_and_reassemble(po, hiplib, engine, world, size):
     assert int(diff.max()) <= 13 and float(diff.float().mean()) < 1.0, (int(diff.max()), float(diff.float().mean()))
 
 
-def test_two_ranks_with_frame_schedule_equal_the_whole_frame(hiplib):
-    """End to end, two processes (gloo, both on this box's one GPU): bands rendered with the whole-frame step
-    schedule (rn_head_reschedule + a 4-byte all-reduce per iteration) and gathered give the single-process frame."""
+@pytest.mark.parametrize("schedule", ["verify", "frame"])
+def test_two_ranks_with_frame_schedule_equal_the_whole_frame(hiplib, schedule):
+    """End to end, two processes (gloo, both on this box's one GPU): bands gathered give the single-process frame -- with the
+    default "verify" schedule (band-local policies, no collective inside the loop, loop counts checked from the gather, a
+    mismatching frame rendered again) and with "frame" (rn_head_reschedule + a 4-byte all-reduce per iteration)."""
     import os
     import socket
     import subprocess
@@ -59,7 +61,7 @@ def test_two_ranks_with_frame_schedule_equal_the_whole_frame(hiplib):
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tools", "tile_check.py"), "--size", "96", "--frames", "3"]
+           "--master-port", str(port), os.path.join(root, "tools", "tile_check.py"), "--size", "96", "--frames", "3", "--schedule", schedule]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "frame 2: max |d|" in r.stdout

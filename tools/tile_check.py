@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--backend", default="gloo")
-    ap.add_argument("--schedule", default="frame")
+    ap.add_argument("--schedule", default="verify")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = int(os.environ.get("LOCAL_RANK", "0")) if args.backend == "nccl" else 0
@@ -38,6 +38,7 @@ def main():
         for i in range(args.frames):
             tpr.step(i)
         frames = [f.cpu() for f in tpr.finish()]
+    print(f"rank {rank}: schedule={tpr.schedule}, frames rendered again with the whole-frame schedule: {tpr.redone}", flush=True)
     ok = True
     if rank == 0:
         ref = SyntheticScene(H=size, W=size, n_frames=8, device=f"cuda:{dev}", opt=default_opt(engine="fused"))
