@@ -23,17 +23,37 @@ def save_checkpoint(model, path, best=False, **extra):
     return path
 
 
-def load_checkpoint(model, checkpoint, map_location=None):
-    """Load a reference checkpoint (path or already-loaded dict). Returns (missing_keys, unexpected_keys)."""
+def load_checkpoint(model, checkpoint, map_location=None, optimizer=None, half_tables=False):
+    """Load a reference checkpoint (path or already-loaded dict).  Returns (missing_keys, unexpected_keys), as
+    `load_state_dict(strict=False)` reports them for the model part (nerf/utils.py:1376-1396).
+
+    optimizer: restored from the checkpoint's `optimizer` entry when it has one (full checkpoints, :1320-1325); a state that
+    does not fit (another parameter grouping) is skipped, as the reference does (:1408-1413).
+    half_tables: build the persistent fp16 copies of the three grid tables now (GridEncoder.half_table) -- what the
+    reference's `-O` mode re-creates by casting every table on every call (gridencoder/grid.py:43-44).
+    `model.checkpoint_meta` receives epoch / global_step / stats when the file has them."""
     if not isinstance(checkpoint, dict):
         checkpoint = torch.load(checkpoint, map_location=map_location, weights_only=False)
     if "model" not in checkpoint:
         model.load_state_dict(checkpoint)
-        return [], []
-    missing, unexpected = model.load_state_dict(checkpoint["model"], strict=False)
-    for key in ("mean_count", "mean_density", "mean_density_torso"):
-        if key in checkpoint:
-            setattr(model, key, checkpoint[key])
+        missing, unexpected = [], []
+    else:
+        missing, unexpected = model.load_state_dict(checkpoint["model"], strict=False)
+        for key in ("mean_count", "mean_density", "mean_density_torso"):
+            if key in checkpoint:
+                setattr(model, key, checkpoint[key])
+        model.checkpoint_meta = {k: checkpoint[k] for k in ("epoch", "global_step", "stats") if k in checkpoint}
+        if optimizer is not None and "optimizer" in checkpoint:
+            try:
+                optimizer.load_state_dict(checkpoint["optimizer"])
+                model.checkpoint_meta["optimizer_loaded"] = True
+            except (ValueError, KeyError, RuntimeError):
+                model.checkpoint_meta["optimizer_loaded"] = False
     if getattr(model, "enc_a", None) is not None:
         model.enc_a = None  # the lip-smoothing state belongs to a stream, not to the weights
+    if half_tables:
+        for name in ("encoder", "encoder_ambient", "torso_encoder"):
+            enc = getattr(model, name, None)
+            if enc is not None and hasattr(enc, "half_table"):
+                enc.half_table()
     return list(missing), list(unexpected)

@@ -132,3 +132,61 @@ def intrinsics_from_fovy(H, W, fovy_deg):
     """(fx, fy, cx, cy) as OrbitCamera.intrinsics computes them (nerf/gui.py:52-55)."""
     focal = H / (2 * math.tan(math.radians(fovy_deg) / 2))
     return np.array([focal, focal, W // 2, H // 2], dtype=np.float32)
+
+
+def nerf_matrix_to_ngp(pose, scale=0.33, offset=(0.0, 0.0, 0.0)):
+    """Dataset pose ([..., 4, 4] or [..., 3, 4], torch or numpy) -> the renderer's convention (nerf/provider.py:19-26): rows
+    (y, z, x) of the input, second and third column negated, translation scaled and offset.  Any leading batch shape, on
+    whatever device the input lives."""
+    is_np = isinstance(pose, np.ndarray)
+    p = torch.as_tensor(pose, dtype=torch.float32)
+    out = torch.zeros(p.shape[:-2] + (4, 4), dtype=torch.float32, device=p.device)
+    src = p[..., [1, 2, 0], :]                                  # new rows 0, 1, 2 <- old rows 1, 2, 0
+    out[..., :3, 0] = src[..., 0]
+    out[..., :3, 1] = -src[..., 1]
+    out[..., :3, 2] = -src[..., 2]
+    out[..., :3, 3] = src[..., 3] * scale + torch.as_tensor(offset, dtype=torch.float32, device=p.device)
+    out[..., 3, 3] = 1.0
+    return out.numpy() if is_np else out
+
+
+def _rotation_mean(rots):
+    """Chordal L2 mean of rotation matrices [..., n, 3, 3] -> [..., 3, 3]: the unit quaternion that is the dominant
+    eigenvector of sum_j q_j q_j^T (what scipy's Rotation.mean() computes)."""
+    m = rots
+    # quaternion (x, y, z, w) of each matrix, numerically safe branch per element
+    t = m[..., 0, 0] + m[..., 1, 1] + m[..., 2, 2]
+    q = torch.stack([m[..., 2, 1] - m[..., 1, 2], m[..., 0, 2] - m[..., 2, 0], m[..., 1, 0] - m[..., 0, 1], 1.0 + t], -1)
+    alt = []
+    for i, (j, k) in enumerate(((1, 2), (2, 0), (0, 1))):
+        v = [None] * 4
+        v[i] = 1.0 + m[..., i, i] - m[..., j, j] - m[..., k, k]
+        v[j] = m[..., j, i] + m[..., i, j]
+        v[k] = m[..., k, i] + m[..., i, k]
+        v[3] = m[..., k, j] - m[..., j, k]
+        alt.append(torch.stack(v, -1))
+    cand = torch.stack([q] + alt, -2)                                      # [..., n, 4 candidates, 4]
+    best = cand.norm(dim=-1).argmax(-1)                                    # the best conditioned candidate
+    q = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+    q = q / q.norm(dim=-1, keepdim=True)
+    K = torch.einsum("...ni,...nj->...ij", q, q)
+    _, vec = torch.linalg.eigh(K.double())
+    x, y, z, w = vec[..., :, -1].float().unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(x.shape + (3, 3))
+
+
+def smooth_camera_path(poses, kernel_size=5):
+    """Moving average of a camera trajectory [N, 4, 4] (nerf/provider.py:29-45): translations averaged over the window
+    [i - K, i + K] clipped to the stream, rotations replaced by the window's rotation mean.  Returns a new array / tensor of
+    the input's kind (the reference overwrites its argument in place)."""
+    is_np = isinstance(poses, np.ndarray)
+    p = torch.as_tensor(poses, dtype=torch.float32).clone()
+    N, K = p.shape[0], kernel_size // 2
+    trans, rots = p[:, :3, 3].clone(), p[:, :3, :3].clone()
+    for i in range(N):                     # windows differ in length only at the two ends; N is the clip length (host-side, once)
+        lo, hi = max(0, i - K), min(N, i + K + 1)
+        p[i, :3, 3] = trans[lo:hi].mean(0)
+        p[i, :3, :3] = _rotation_mean(rots[lo:hi])
+    return p.numpy() if is_np else p

@@ -93,6 +93,8 @@ def make_flow(env):
     sd = m.state_dict()
     out["param_names"] = np.array(sorted(sd.keys()))
     out["param_sha256"] = np.array([sha(t2n(sd[k])) for k in sorted(sd.keys())])
+    out["param_shapes"] = np.array(["x".join(str(d) for d in sd[k].shape) for k in sorted(sd.keys())])
+    out["param_dtypes"] = np.array([str(sd[k].dtype) for k in sorted(sd.keys())])
 
     # ---- inputs of the path, from the reference's own utilities
     pose = scene.poses[3:4]
@@ -106,6 +108,12 @@ def make_flow(env):
     for idx in (0, 2, 5, 7):
         out[f"aud_window_{idx}"] = t2n(ref_utils.get_audio_features(scene.aud_features, 2, idx))
     out["aud_features"] = t2n(scene.aud_features)
+    # dataset-side pose utilities (nerf/provider.py:19-45): axis convention of the loader, trajectory smoothing
+    import nerf.provider as ref_provider
+    raw = t2n(scene.poses).astype(np.float64)
+    out["ngp_pose_in"] = raw[5]
+    out["ngp_pose_out"] = ref_provider.nerf_matrix_to_ngp(raw[5], scale=4, offset=[0.1, -0.2, 0.3])
+    out["smooth_path"] = ref_provider.smooth_camera_path(t2n(scene.poses).copy(), 5)
 
     # ---- per-sample network (network.py:222-325), torso (188-219), audio (170-185)
     rng = np.random.default_rng(11)

@@ -34,3 +34,36 @@ def test_reference_checkpoint_round_trip(hiplib, tmp_path):
               "individual_codes", "individual_codes_torso", "density_bitfield", "density_grid", "density_grid_torso",
               "aabb_train", "aabb_infer", "step_counter"):
         assert k in keys, k
+
+
+def test_state_dict_layout_is_the_reference_models(hiplib):
+    """Names, shapes and dtypes of every state-dict entry of the reference's NeRFNetwork (tests/golden/reference_flow.npz, taken
+    from the reference class itself): a file written by the reference's Trainer.save_checkpoint has exactly these."""
+    import numpy as np
+    from radnerf.scene import SyntheticScene, default_opt
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_flow.npz"))
+    sd = SyntheticScene(H=8, W=8, n_frames=8, device="cpu", opt=default_opt()).model.state_dict()
+    names = sorted(sd.keys())
+    assert names == [str(n) for n in gold["param_names"]]
+    assert ["x".join(str(d) for d in sd[k].shape) for k in names] == [str(v) for v in gold["param_shapes"]]
+    assert [str(sd[k].dtype) for k in names] == [str(v) for v in gold["param_dtypes"]]
+
+
+def test_full_checkpoint_restores_optimizer_and_meta(hiplib, tmp_path):
+    from radnerf.checkpoint import load_checkpoint, save_checkpoint
+    from radnerf.scene import SyntheticScene, default_opt
+    from radnerf.train import make_optimizer
+    opt = default_opt(torso=False)
+    a = SyntheticScene(H=8, W=8, n_frames=8, device="cpu", opt=opt, seed=0).model
+    oa = make_optimizer(a, fused=False)
+    (a.sigma_net.net[0].weight.sum() + a.individual_codes.sum()).backward()
+    oa.step()
+    path = save_checkpoint(a, os.path.join(tmp_path, "ngp_ep0003.pth"), epoch=3, global_step=77, stats={"loss": [1.0]},
+                           optimizer=oa.state_dict())
+    b = SyntheticScene(H=8, W=8, n_frames=8, device="cpu", opt=opt, seed=5).model
+    ob = make_optimizer(b, fused=False)
+    missing, unexpected = load_checkpoint(b, path, optimizer=ob, half_tables=False)
+    assert missing == [] and unexpected == []
+    assert b.checkpoint_meta["epoch"] == 3 and b.checkpoint_meta["global_step"] == 77 and b.checkpoint_meta["optimizer_loaded"]
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)

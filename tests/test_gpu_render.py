@@ -90,3 +90,27 @@ def test_device_ray_generation_matches_get_rays(hiplib, H, W):
     assert torch.equal(got["rays_o"], want["rays_o"].contiguous())
     assert (got["rays_d"] - want["rays_d"]).abs().max().item() <= 2e-7
     assert (got["rays_d"].norm(dim=-1) - 1).abs().max().item() <= 2e-7
+
+
+def test_frame_sink_hands_frames_to_pinned_host_memory_and_times_them(hiplib):
+    """f-4: uint8 frames of the blend kernel leave through a side stream into a ring of pinned slots; per-frame event timing."""
+    from radnerf.output import FrameSink, FrameTimer
+    from radnerf.scene import SyntheticScene, default_opt
+    scene = SyntheticScene(H=64, W=64, n_frames=8, device="cuda", opt=default_opt(engine="fused"))
+    sink, timer = FrameSink(64, 64, slots=4), FrameTimer()
+    want = []
+    with torch.no_grad():
+        for i in range(4):
+            timer.start()
+            out = scene.render(i, want_u8=True)
+            timer.stop()
+            sink.push(out["image_u8"], tag=i)
+            want.append((out["image"].reshape(64, 64, 3) * 255).to(torch.uint8).cpu().numpy())
+        with pytest.raises(RuntimeError):
+            sink.push(out["image_u8"], tag=99)                    # ring full until the host takes frames
+    for i in range(4):
+        tag, frame = sink.pop()
+        assert tag == i and np.array_equal(frame, want[i])
+    assert sink.pop() is None
+    s = timer.summary()
+    assert s["frames"] == 4 and 0 < s["p50"] <= s["p95"] and s["fps"] > 0
