@@ -97,7 +97,31 @@ __global__ void __launch_bounds__(256) k_pack_nerf_h16(RawW w, float *__restrict
 // the matrix pipe is far from binding in these kernels, so the 2x instruction count is not measurable.
 // (tools/repro_mfma_k16.sh rebuilds this file with -DRN_MFMA_K16=1 and runs tools/check_determinism.py to show it.)
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
-#if RN_MFMA_K16
+#if RN_MFMA_K16 == 3
+    // control for the experiment below: the K = 8 instruction (x2) in exactly the same asm-with-wait-states form
+    typedef _Float16 f16x4c __attribute__((ext_vector_type(4)));
+    const f16x4c ca0 = {a[0], a[1], a[2], a[3]}, ca1 = {a[4], a[5], a[6], a[7]};
+    const f16x4c cb0 = {b[0], b[1], b[2], b[3]}, cb1 = {b[4], b[5], b[6], b[7]};
+    f32x16 dc = c;
+    asm volatile("s_nop 15\n\ts_nop 15\n\tv_mfma_f32_32x32x8_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(dc) : "v"(ca0), "v"(cb0));
+    asm volatile("s_nop 15\n\ts_nop 15\n\tv_mfma_f32_32x32x8_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(dc) : "v"(ca1), "v"(cb1));
+    return dc;
+#elif RN_MFMA_K16 == 2
+    // experiment (tools/repro_mfma_k16_waitstates.sh): the K = 16 instruction and 80 wait states in ONE asm statement, so that
+    // nothing of this wave -- in particular no VALU write to the A / B source registers -- can issue while the matrix pipe may
+    // still be reading them.  If the launch-to-launch deviations survive this, they are not a same-wave write-after-read hazard.
+    f32x16 d = c;
+#if RN_MFMA_K16_LEAD   // also 32 wait states BEFORE it: whatever wrote a / b / d has long retired (the asm hides the MFMA from hipcc's hazard pass)
+    asm volatile("s_nop 15\n\ts_nop 15\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(d) : "v"(a), "v"(b));
+#else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(d) : "v"(a), "v"(b));
+#endif
+    return d;
+#elif RN_MFMA_K16
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #endif
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
