@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--latency-every", type=int, default=8,
                     help="bracket every n-th timed frame with HIP events on the render stream: mean / p50 / p95 frame latency "
                          "(SURVEY 8(d); the GUI of the reference times a frame the same way, nerf/gui.py:174-202)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="frames in flight on this GPU (HIP streams the frames alternate between); 2 lets one frame's small kernels run "
+                         "beside the other frame's network kernel (throughput mode; needs --audio-batch > 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -289,7 +292,8 @@ def main():
             scene.model.sigma_net.net[-1].weight[0].abs_().mul_(80.0)
     tile = args.workload == "tile"
     fpr = (TileParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint) if tile else
-           FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint, audio_batch=args.audio_batch))
+           FrameParallelRenderer(scene, rank, world, dist, speculate_loop=not args.no_loop_hint, audio_batch=args.audio_batch,
+                                 streams=args.streams))
 
     def barrier():
         if dist is not None:
@@ -319,9 +323,10 @@ def main():
                         hip.prof_pause((s - W) % max(args.time_every, 1) != 0)
                     if (s - W) % le == le // 2:     # never a frame whose kernel dispatches carry timing events
                         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        ea.record()
+                        rs = fpr.render_stream(s) if hasattr(fpr, "render_stream") else torch.cuda.current_stream()
+                        ea.record(rs)
                         fpr.step(s)
-                        eb.record()
+                        eb.record(rs)
                         lat_events.append((ea, eb))
                     else:
                         fpr.step(s)
@@ -436,12 +441,12 @@ def main():
                                  "note": "SURVEY 8(d) proposes semi-axes (0.33, 0.42, 0.33); (0.40, 0.42, 0.40) reproduces the published "
                                          "trace's 31 % of rays hitting the head at this pose"},
                        "audio_batch": args.audio_batch if engine == "fused" and not tile else 0,
+                       "frames_in_flight": getattr(fpr, "n_streams", 1),
                        "collectives": ({"per_frame": 1, "kind": "all_gather of uint8 band rows (+ 68 B of loop counts that verify the band-local "
                                         "step schedules)", "schedule": getattr(fpr, "schedule", None), "frames_redone_exactly": getattr(fpr, "redone", 0)}
                                        if tile else {"per_frame": 1.0 / max(getattr(fpr, "gather_every", 1), 1), "kind": "gather of uint8 frames to rank 0, "
                                                      f"{getattr(fpr, 'gather_every', 1)} frames per collective"}) if world > 1 else None,
-                       "loop_iterations_enqueued": (getattr(getattr(scene.model, "_fused_state", None), "loop_hint", None)
-                                                    or scene.opt.max_steps),
+                       "loop_iterations_enqueued": (getattr(scene.model, "_fused_loop_hint", None) or scene.opt.max_steps),
                        "parallelism": f"{'tile' if tile else 'frame'}-parallel x{world}"},
             # tile-parallel: rank 0 counts its own band's samples; the bands are interleaved, so x world is the frame's
             "samples_per_s": live_pf * (world if tile else 1) * fps, "samples_per_frame": live_pf * (world if tile else 1),

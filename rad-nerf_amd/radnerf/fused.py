@@ -272,12 +272,24 @@ class LoopStats(dict):
         return super().__repr__()
 
 
+def _all_states(model):
+    """Every FusedState of the model: one per HIP stream frames are enqueued on (a renderer that keeps two frames in flight
+    uses two streams, and each needs its own loop state and scratch)."""
+    states = getattr(model, "_fused_states", None)
+    return [st for st in states.values() if st.model is model and st._N] if states else []
+
+
 def loop_counters(model):
-    """Cumulative device-side loop counters (iterations, live samples, sample slots); synchronises."""
-    st = getattr(model, "_fused_state", None)
-    if st is None or st._N == 0:
+    """Cumulative device-side loop counters (iterations, live samples, sample slots), summed over the model's streams;
+    synchronises."""
+    states = _all_states(model)
+    if not states:
         return None
-    return st.state[ST_ITERS:ST_SLOTS + 1].cpu().tolist()
+    tot = [0, 0, 0]
+    for st in states:
+        cur = st.state[ST_ITERS:ST_SLOTS + 1].cpu().tolist()
+        tot = [(a + b) & 0xFFFFFFFF for a, b in zip(tot, cur)]
+    return tot
 
 
 def loop_history(model, n):
@@ -289,24 +301,31 @@ def loop_history(model, n):
 
 def unfinished_frames(model):
     """Frames (cumulative) whose loop was cut short by a speculative iteration count (set_loop_hint); synchronises."""
-    st = getattr(model, "_fused_state", None)
-    if st is None or st._N == 0:
-        return 0
-    return int(st.state[ST_UNFINISHED].item())
+    return sum(int(st.state[ST_UNFINISHED].item()) for st in _all_states(model))
 
 
 def set_loop_hint(model, iterations):
     """Enqueue only `iterations` loop iterations per frame from now on (None: all max_steps, the default).  The device
     records frames for which that was not enough (unfinished_frames); the caller checks it where it synchronises and
     renders those frames again.  Meant for streams whose iteration count is known from earlier frames."""
-    _state(model).loop_hint = None if iterations is None else max(1, int(iterations))
+    hint = None if iterations is None else max(1, int(iterations))
+    object.__setattr__(model, "_fused_loop_hint", hint)
+    for st in (getattr(model, "_fused_states", None) or {}).values():
+        st.loop_hint = hint
 
 
 def _state(model):
-    st = getattr(model, "_fused_state", None)
+    """The model's state for the CURRENT stream (created on first use)."""
+    states = getattr(model, "_fused_states", None)
+    if states is None:
+        states = {}
+        object.__setattr__(model, "_fused_states", states)
+    key = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+    st = states.get(key)
     if st is None or st.model is not model:
         st = FusedState(model)
-        object.__setattr__(model, "_fused_state", st)
+        st.loop_hint = getattr(model, "_fused_loop_hint", None)
+        states[key] = st
     return st
 
 

@@ -110,7 +110,7 @@ class LoopHintTooSmall(RuntimeError):
 
 class FrameParallelRenderer(_Bookkeeping):
     def __init__(self, scene, rank=0, world=1, dist=None, gather=True, speculate_loop=False, gather_every=8, audio_batch=0,
-                 gather_to="rank0"):
+                 gather_to="rank0", streams=1):
         """speculate_loop (fused engine): after the first finish() the renderer knows how many loop iterations the
         stream's frames take (device counters) and enqueues that many + 2 per frame instead of max_steps, skipping
         the no-op launches behind them; the device flags any frame for which that was not enough and finish() raises
@@ -136,6 +136,15 @@ class FrameParallelRenderer(_Bookkeeping):
         # per-frame bias blocks of this rank's next K frames are computed together -- 4 launches per K frames instead of 4
         # per frame; the frames then start at the ray prologue.  Same numbers: the recurrence runs over every global frame
         # in order (the other ranks' included), exactly as _advance_audio does frame by frame.
+        # streams = 2 (fused engine): consecutive frames alternate between two HIP streams, so one frame's small latency-bound
+        # kernels (ray prologue, compositor, compaction + march, torso) run beside the other frame's network kernel instead of
+        # leaving most CUs idle; the persistent network kernels themselves still take turns (two of their 96 KB LDS images do not
+        # fit one CU).  Frames stay independent: each stream has its own loop state, scratch and ray buffers; the audio codes of
+        # a batch are computed on the default stream and both render streams wait for that event.  Throughput mode -- a single
+        # frame's latency gets longer.
+        self.n_streams = max(1, int(streams)) if getattr(scene.opt, "engine", "ops") == "fused" and scene.device.type == "cuda" else 1
+        self._streams = [torch.cuda.Stream(device=scene.device) for _ in range(self.n_streams)] if self.n_streams > 1 else None
+        self._audio_ready = None
         self.audio_batch = max(0, int(audio_batch))
         self._ab = None                  # (first step, smoothed codes [K, dim], bias blocks [K, 192])
         self._ab_next = None             # the step the prepared batch expects next
@@ -178,9 +187,33 @@ class FrameParallelRenderer(_Bookkeeping):
         code = m.individual_codes[0] if m.individual_dim > 0 else None
         self._ab = (step, states, fused.frame_bias_batch(m, states, sc.eye, code))
         self._ab_next = step
+        if self._streams:
+            self._audio_ready = torch.cuda.Event()
+            self._audio_ready.record()
 
     # -- one step = one frame on this rank ----------------------------------------------------------
+    def render_stream(self, step):
+        """The stream step `step`'s frame is enqueued on (the current stream unless streams > 1)."""
+        return self._streams[step % self.n_streams] if self._streams else torch.cuda.current_stream(self.scene.device)
+
     def step(self, step):
+        if self._streams:
+            if not self._audio_batch_ok():
+                raise RuntimeError("streams > 1 needs audio_batch > 0 (the per-frame audio recurrence would serialise the frames)")
+            if self._ab is None or step != self._ab_next or step - self._ab[0] >= self._ab[1].shape[0]:
+                for st in self._streams:                       # the batch buffers about to be replaced may still be read
+                    torch.cuda.current_stream(self.scene.device).wait_stream(st)
+                self._prepare_audio(step)
+            side = self._streams[step % self.n_streams]
+            side.wait_event(self._audio_ready)
+            with torch.cuda.stream(side):
+                u8 = self._step(step)
+            if self.gather:                                        # collectives are issued from the default stream
+                torch.cuda.current_stream(self.scene.device).wait_stream(side)
+            return u8
+        return self._step(step)
+
+    def _step(self, step):
         g = frame_of(step, self.rank, self.world)
         if self._audio_batch_ok():
             if self._ab is None or step != self._ab_next or step - self._ab[0] >= self._ab[1].shape[0]:
@@ -246,6 +279,9 @@ class FrameParallelRenderer(_Bookkeeping):
         if done:
             self.frames_u8 = done[-1]
         self.pending = []
+        if self._streams:
+            for st in self._streams:
+                st.synchronize()
         if self.speculate_loop:
             self._update_loop_hint()
         return done

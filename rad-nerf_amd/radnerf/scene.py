@@ -133,9 +133,11 @@ class SyntheticScene:
         base = dict(auds=get_audio_features(self.aud_features, self.opt.att, i), bg_coords=self.bg_coords, poses=self.poses6[i:i + 1],
                     eye=self.eye, index=0, bg_color=self.bg_color)
         if lazy_rays and self._lazy_rays():
-            if getattr(self, "_ray_bufs", None) is None:
-                self._ray_bufs = (torch.empty(1, self.H * self.W, 3, device=self.device), torch.empty(1, self.H * self.W, 3, device=self.device))
-            return dict(base, rays_o=self._ray_bufs[0], rays_d=self._ray_bufs[1], ray_source=(self.poses[i], self.intrinsics, self.W))
+            bufs = self.__dict__.setdefault("_ray_bufs", {})
+            key = torch.cuda.current_stream().cuda_stream          # frames in flight on different streams must not share them
+            if key not in bufs:
+                bufs[key] = (torch.empty(1, self.H * self.W, 3, device=self.device), torch.empty(1, self.H * self.W, 3, device=self.device))
+            return dict(base, rays_o=bufs[key][0], rays_d=bufs[key][1], ray_source=(self.poses[i], self.intrinsics, self.W))
         if i not in self._rays:
             if self.device.type == "cuda" and getattr(self.opt, "engine", "ops") == "fused" and getattr(self.opt, "ray_engine", "fused") == "fused":
                 from . import fused                                   # one kernel (rn_get_rays) instead of ~12 torch launches

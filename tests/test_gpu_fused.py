@@ -468,3 +468,22 @@ def test_audio_batches_equal_the_per_frame_audio_path(hiplib):
             fb = FrameParallelRenderer(b, rank, world, None, gather=False)
             for s in range(7):                                     # a full batch, then a partial one
                 assert torch.equal(fa.step(s), fb.step(s)), (world, s)
+
+
+def test_two_frames_in_flight_render_the_same_frames(hiplib):
+    """FrameParallelRenderer(streams=2): consecutive frames alternate between two HIP streams (own loop state, scratch and ray
+    buffers each); the frames are those of the one-stream renderer, bit for bit."""
+    from radnerf.parallel import FrameParallelRenderer
+    a, b = _scene(96, "fused"), _scene(96, "fused")
+    with torch.no_grad():
+        fa = FrameParallelRenderer(a, 0, 1, None, gather=False, audio_batch=4, streams=2, speculate_loop=True)
+        fb = FrameParallelRenderer(b, 0, 1, None, gather=False, audio_batch=4)
+        got = [fa.step(s) for s in range(6)]
+        fa.finish()
+        got += [fa.step(s) for s in range(6, 11)]          # after finish(): with the learned loop length
+        fa.finish()
+        want = [fb.step(s) for s in range(11)]
+        fb.finish()
+    torch.cuda.synchronize()
+    for s, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), s
