@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight on this GPU (HIP streams the frames alternate between); 2 lets one frame's small kernels run "
                          "beside the other frame's network kernel (throughput mode; needs --audio-batch > 0)")
+    ap.add_argument("--loop-launch", default="split", choices=["coop", "split"],
+                    help="fused engine: compositor + compaction + next march of a loop iteration in one launch with a grid-wide "
+                         "barrier inside (2 launches per iteration) / a launch each for compositor and compaction (3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="0 = same size as the GPU workload")
     return ap.parse_args()
@@ -286,7 +289,7 @@ def main():
     K, W = args.steps, args.warmup
     n_frames = 250
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
-                           opt=default_opt(engine=engine, mlp_dtype=args.mlp, **GRIDS[args.grid]))
+                           opt=default_opt(engine=engine, mlp_dtype=args.mlp, loop_launch=args.loop_launch, **GRIDS[args.grid]))
     if args.regime == "A":
         with torch.no_grad():
             scene.model.sigma_net.net[-1].weight[0].abs_().mul_(80.0)
@@ -441,7 +444,7 @@ def main():
                                  "note": "SURVEY 8(d) proposes semi-axes (0.33, 0.42, 0.33); (0.40, 0.42, 0.40) reproduces the published "
                                          "trace's 31 % of rays hitting the head at this pose"},
                        "audio_batch": args.audio_batch if engine == "fused" and not tile else 0,
-                       "frames_in_flight": getattr(fpr, "n_streams", 1),
+                       "frames_in_flight": getattr(fpr, "n_streams", 1), "loop_launch": getattr(scene.opt, "loop_launch", "split"),
                        "collectives": ({"per_frame": 1, "kind": "all_gather of uint8 band rows (+ 68 B of loop counts that verify the band-local "
                                         "step schedules)", "schedule": getattr(fpr, "schedule", None), "frames_redone_exactly": getattr(fpr, "redone", 0)}
                                        if tile else {"per_frame": 1.0 / max(getattr(fpr, "gather_every", 1), 1), "kind": "gather of uint8 frames to rank 0, "

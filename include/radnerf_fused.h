@@ -110,7 +110,8 @@ typedef struct {
     float *xyzs, *dirs, *deltas;          /* [N,3] [N,3] [N,2] */
     float *sigmas, *rgbs;                 /* [N] [N,3] */
     int32_t *state;                       /* [RN_HEAD_STATE_INTS] */
-    uint32_t *block_counts;               /* [3 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums x 2 */
+    uint32_t *block_counts;               /* [3 * (ceil(N/256) + 1)]: survivor counts | live-sample partial sums x 2; zeroed once
+                                             before first use when RN_LOOP_COOP is used */
     int32_t *live_slots;                  /* [N] or NULL.  Scratch for the list of live sample slots of an iteration: the
                                              marchers write it and the network kernel then runs over st[6] live samples
                                              instead of all n_alive * n_step slots (rays that end in the middle of their
@@ -137,9 +138,14 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
  *                          kernel), so the call starts with the network launch;
  *   RN_LOOP_CLOSE_FRAME    the call's last compaction is the frame's last: it also does what rn_head_check_done does (flags the
  *                          frame in state[RN_HEAD_ST_UNFINISHED] when the loop was still active) and leaves both live-sample
- *                          counters (state[6], state[14]) at zero, which rn_frame_begin relies on. */
+ *                          counters (state[6], state[14]) at zero, which rn_frame_begin relies on;
+ *   RN_LOOP_COOP           compositor + compaction (+ next march) of an iteration run as ONE launch with a grid-wide barrier inside
+ *                          (2 launches per iteration instead of 3; same results).  The launch needs its <= 512 workgroups of 256
+ *                          threads resident together: use it from at most three streams at a time on one device, and not while
+ *                          another kernel may hold compute units indefinitely.  state[RN_HEAD_ST_STALLED] must stay 0. */
 #define RN_LOOP_FIRST_MARCHED 1u
 #define RN_LOOP_CLOSE_FRAME 2u
+#define RN_LOOP_COOP 4u
 int rn_head_iterate_ex(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid_t *grid_amb, const float *packed,
                        const float *bias, uint32_t first_iter, uint32_t n_iters, int mlp_dtype, uint32_t flags,
                        rn_stream_t stream);
@@ -166,6 +172,9 @@ int rn_head_reschedule(const rn_head_t *h, uint32_t iter_done, uint32_t schedule
 #define RN_HEAD_ST_LIVE 17       /* live samples evaluated */
 #define RN_HEAD_ST_SLOTS 18      /* sample slots n_alive * n_step summed over iterations */
 #define RN_HEAD_ST_UNFINISHED 19 /* frames whose loop was still active when rn_head_check_done looked (see below) */
+#define RN_HEAD_ST_BARRIER 20    /* launch counter of the RN_LOOP_COOP kernels (tags the survivor counts of a launch; never reset) */
+#define RN_HEAD_ST_STALLED 22    /* RN_LOOP_COOP: workgroups that gave up waiting at the in-launch barrier (must stay 0; a frame
+                                    rendered while it moved is invalid and has to be rendered again without RN_LOOP_COOP) */
 #define RN_HEAD_ST_HIST 32       /* state[32 + i], i = 0 .. max_steps (<= 31): live rays entering loop iteration i of the frame in
                                     flight (0 once the loop is over).  A shard of a frame publishes these so the ranks can verify,
                                     after the fact, that their band-local step schedules were the whole frame's (radnerf/parallel.py) */

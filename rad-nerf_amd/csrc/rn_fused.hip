@@ -648,18 +648,22 @@ k_frame_begin(RaySource rs, float *__restrict__ rays_o, float *__restrict__ rays
     if (threadIdx.x == 0) block_live[blockIdx.x] = total;
 }
 
-// raymarching.cu:942-1029 + per-block survivor counts for the compaction that follows
-__global__ void __launch_bounds__(kLoopBlock)
-k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__restrict__ rays_alive,
-                 float *__restrict__ rays_t, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                 const float *__restrict__ deltas, float *__restrict__ weights_sum, float *__restrict__ depth,
-                 float *__restrict__ image, uint32_t *__restrict__ block_counts, int32_t *__restrict__ st_next) {
-    __shared__ uint32_t wave_cnt[kLoopBlock / kWave];
-    if (!st[4]) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st_next[6] = 0;  // the marchers of the next iteration count their live samples here
-    const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
-    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
-    if (blockIdx.x * kLoopBlock >= n_alive) return;
+// raymarching.cu:942-1029 + per-block survivor counts for the compaction that follows.  One chunk = kLoopBlock consecutive
+// entries of the alive list; COOP: the counts cross workgroups INSIDE a launch (k_head_step), so they are written with
+// agent-scope atomic stores (the per-XCD L2s are not coherent with each other for plain stores).
+constexpr uint32_t kTagShift = 10;               // a chunk has <= kLoopBlock = 256 survivors
+constexpr uint32_t kTagMask = (1u << 22) - 1u;
+constexpr uint32_t kBarrierPolls = 1u << 20;     // ~1 s of polling before a workgroup gives up waiting for a chunk's count
+
+template <bool COOP>
+__device__ __forceinline__ void composite_chunk(uint32_t c, uint32_t n_alive, uint32_t n_step, float T_thresh,
+                                                int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+                                                const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                const float *__restrict__ deltas, float *__restrict__ weights_sum,
+                                                float *__restrict__ depth, float *__restrict__ image,
+                                                uint32_t *__restrict__ block_counts, uint32_t *wave_cnt /* LDS [kLoopBlock / kWave] */,
+                                                uint32_t tag = 0) {
+    const uint32_t n = c * kLoopBlock + threadIdx.x;
     bool survive = false;
     if (n < n_alive) {
         const int index = rays_alive[n];
@@ -697,8 +701,29 @@ k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__rest
     if (threadIdx.x == 0) {
         uint32_t s = 0;
         for (int w = 0; w < kLoopBlock / kWave; w++) s += wave_cnt[w];
-        block_counts[blockIdx.x] = s;
+        if constexpr (COOP) {
+            // count + launch tag in one word: the word IS the chunk's arrival flag (k_head_step).  The first store of workgroup
+            // 0 is a release: its reset of the next live-sample counter must be visible before anybody passes the barrier.
+            if (c == 0) __hip_atomic_store(&block_counts[c], (tag << kTagShift) | s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(&block_counts[c], (tag << kTagShift) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            block_counts[c] = s;
+        }
     }
+}
+
+__global__ void __launch_bounds__(kLoopBlock)
+k_head_composite(const int32_t *__restrict__ st, float T_thresh, int32_t *__restrict__ rays_alive,
+                 float *__restrict__ rays_t, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                 const float *__restrict__ deltas, float *__restrict__ weights_sum, float *__restrict__ depth,
+                 float *__restrict__ image, uint32_t *__restrict__ block_counts, int32_t *__restrict__ st_next) {
+    __shared__ uint32_t wave_cnt[kLoopBlock / kWave];
+    if (!st[4]) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st_next[6] = 0;  // the marchers of the next iteration count their live samples here
+    const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
+    if (blockIdx.x * kLoopBlock >= n_alive) return;
+    composite_chunk<false>(blockIdx.x, n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                           block_counts, wave_cnt);
 }
 
 // stable compaction (renderer.py:258) + loop control (renderer.py:242-249, 262) for the next iteration and, with MARCH,
@@ -716,34 +741,48 @@ struct MarchArgs {
     int32_t *live_slots;
 };
 
-template <bool MARCH>
-__global__ void __launch_bounds__(kLoopBlock)
-k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps,
-               const int32_t *__restrict__ rays_in, int32_t *__restrict__ rays_out,
-               const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats,
-               MarchArgs m, uint32_t close_frame, uint32_t iter) {
+// What a launch does when the loop is already over (st[4] == 0): carry the state over, close the frame's counters.
+__device__ __forceinline__ void loop_idle(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, int32_t *__restrict__ stats,
+                                          uint32_t close_frame, uint32_t iter) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) st_next[threadIdx.x] = st[threadIdx.x];
+    // close_frame (last compaction of a frame's loop): both live-sample counters back to zero for the next frame's
+    // prologue; the loop is over, so rn_head_check_done has nothing to flag
+    if (close_frame && blockIdx.x == 0 && threadIdx.x == 0) { stats[6] = 0; stats[8 + 6] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && iter + 1 < 32) stats[RN_HEAD_ST_HIST + iter + 1] = 0;
+}
+
+// Chunk c of the n_blocks chunks of the alive list (see k_head_compact).  COOP: the survivor counts were written by other
+// workgroups of THIS launch -> agent-scope atomic loads.
+template <bool MARCH, bool COOP>
+__device__ __forceinline__ void compact_chunk(uint32_t c, uint32_t n_blocks, const int32_t *__restrict__ st, int32_t *__restrict__ st_next,
+                                              uint32_t N, uint32_t max_steps, const int32_t *__restrict__ rays_in,
+                                              int32_t *__restrict__ rays_out, const uint32_t *__restrict__ block_counts,
+                                              const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats, const MarchArgs &m,
+                                              uint32_t close_frame, uint32_t iter, uint32_t tag = 0) {
     __shared__ uint32_t red[kLoopBlock / kWave];
     __shared__ uint32_t red_live[kLoopBlock / kWave];
     __shared__ uint32_t red_all[kLoopBlock / kWave];
     __shared__ uint32_t wave_off[kLoopBlock / kWave];
-    if (!st[4]) {
-        if (blockIdx.x == 0 && threadIdx.x < 8) st_next[threadIdx.x] = st[threadIdx.x];
-        // close_frame (last compaction of a frame's loop): both live-sample counters back to zero for the next frame's
-        // prologue; the loop is over, so rn_head_check_done has nothing to flag
-        if (close_frame && blockIdx.x == 0 && threadIdx.x == 0) { stats[6] = 0; stats[8 + 6] = 0; }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && iter + 1 < 32) stats[RN_HEAD_ST_HIST + iter + 1] = 0;
-        return;
-    }
     const uint32_t n_alive = (uint32_t)st[0];
-    const uint32_t n_blocks = (n_alive + kLoopBlock - 1) / kLoopBlock;
-    if (blockIdx.x >= n_blocks) return;
-    const bool last = blockIdx.x == n_blocks - 1;
+    const bool last = c == n_blocks - 1;
 
     uint32_t part = 0, live = 0, all = 0;
     for (uint32_t b = threadIdx.x; b < n_blocks; b += kLoopBlock) {
-        const uint32_t c = block_counts[b];
-        all += c;
-        part += b < blockIdx.x ? c : 0u;
+        uint32_t cnt;
+        if constexpr (COOP) {   // the grid-wide barrier: wait until chunk b's count of THIS launch has arrived
+            uint32_t polls = 0;
+            cnt = __hip_atomic_load(&block_counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((cnt >> kTagShift) != tag) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > kBarrierPolls) { atomicAdd(&stats[RN_HEAD_ST_STALLED], 1); break; }
+                cnt = __hip_atomic_load(&block_counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            cnt &= (1u << kTagShift) - 1u;
+        } else {
+            cnt = block_counts[b];
+        }
+        all += cnt;
+        part += b < c ? cnt : 0u;
     }
     if (last) {  // the last workgroup also adds up the live-sample partial sums of this iteration's march
         const uint32_t n_live = st[5] ? (uint32_t)st[5] : n_blocks;
@@ -757,7 +796,7 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
     uint32_t offset = 0, n_next = 0;
     for (int w = 0; w < kLoopBlock / kWave; w++) { offset += red[w]; n_next += red_all[w]; }
 
-    const uint32_t n = blockIdx.x * kLoopBlock + threadIdx.x;
+    const uint32_t n = c * kLoopBlock + threadIdx.x;
     const int32_t v = (n < n_alive) ? rays_in[n] : -1;
     const bool keep = v >= 0;
     const unsigned long long mask = __ballot(keep);
@@ -783,7 +822,7 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
             stats[6] = 0; stats[8 + 6] = 0;   // no marcher runs after the frame's last compaction
         }
         if (MARCH && active_next) {
-            st_next[5] = (int32_t)n_blocks;  // the partial sums written below are indexed by THIS launch's workgroups
+            st_next[5] = (int32_t)n_blocks;  // the partial sums written below are indexed by THIS launch's chunks
             atomicAdd(&stats[RN_HEAD_ST_ITERS], 1);
             atomicAdd(&stats[RN_HEAD_ST_SLOTS], (int32_t)(n_next * n_step_next));
         }
@@ -802,8 +841,65 @@ k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, ui
         }
         __shared__ uint32_t sh[kLoopBlock / kWave + 1];
         const uint32_t total = list_live_slots(emitted, base, st_next + 6, m.live_slots, sh);
-        if (threadIdx.x == 0) m.block_live_next[blockIdx.x] = total;
+        if (threadIdx.x == 0) m.block_live_next[c] = total;
     }
+}
+
+template <bool MARCH>
+__global__ void __launch_bounds__(kLoopBlock)
+k_head_compact(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps,
+               const int32_t *__restrict__ rays_in, int32_t *__restrict__ rays_out,
+               const uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats,
+               MarchArgs m, uint32_t close_frame, uint32_t iter) {
+    if (!st[4]) { loop_idle(st, st_next, stats, close_frame, iter); return; }
+    const uint32_t n_blocks = ((uint32_t)st[0] + kLoopBlock - 1) / kLoopBlock;
+    if (blockIdx.x >= n_blocks) return;
+    compact_chunk<MARCH, false>(blockIdx.x, n_blocks, st, st_next, N, max_steps, rays_in, rays_out, block_counts, block_live, stats, m,
+                                close_frame, iter);
+}
+
+// Compositor + compaction (+ next march) of one loop iteration in ONE launch: what k_head_composite and k_head_compact do,
+// with a grid-wide barrier where the kernel boundary was (the compaction needs every chunk's survivor count: the new live
+// count decides the next n_step).  At most kStepGrid workgroups take part, each walking chunks b, b + G, ...; with <= 80
+// VGPRs and 256 threads six of them fit on a CU, so kStepGrid workgroups are co-resident three times over on this chip --
+// launches of up to three streams may overlap (the host falls back to the two-kernel form beyond that).
+// The barrier has no counter (512 same-address atomics cost ~25 us here: they execute one after the other at the memory
+// side): a chunk's survivor count is stored together with a per-launch tag (state[RN_HEAD_ST_BARRIER], bumped by every
+// launch, never reset), and the summation every workgroup does anyway waits for each word to carry this launch's tag.
+// Exit condition every wave reaches: the wait is bounded; running into the bound counts in state[RN_HEAD_ST_STALLED]
+// (the host treats such a frame as not rendered) and the workgroup carries on.
+constexpr uint32_t kStepGrid = 512;
+
+template <bool MARCH>
+__global__ void __launch_bounds__(kLoopBlock, 6)
+k_head_step(const int32_t *__restrict__ st, int32_t *__restrict__ st_next, uint32_t N, uint32_t max_steps, float T_thresh,
+            int32_t *rays_in, int32_t *__restrict__ rays_out, float *rays_t /* = m.rays_t */,
+            const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *deltas /* = m.deltas */,
+            float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+            uint32_t *block_counts, const uint32_t *__restrict__ block_live, int32_t *__restrict__ stats,
+            MarchArgs m, uint32_t close_frame, uint32_t iter) {
+    __shared__ uint32_t wave_cnt[kLoopBlock / kWave];
+    if (!st[4]) { loop_idle(st, st_next, stats, close_frame, iter); return; }
+    const uint32_t n_alive = (uint32_t)st[0], n_step = (uint32_t)st[2];
+    const uint32_t n_chunks = (n_alive + kLoopBlock - 1) / kLoopBlock;
+    const uint32_t G = n_chunks < gridDim.x ? n_chunks : gridDim.x;
+    if (blockIdx.x >= G) return;
+    const uint32_t epoch = (uint32_t)stats[RN_HEAD_ST_BARRIER];   // written by the previous launch of this state's stream
+    const uint32_t tag = epoch % kTagMask + 1u;                   // 1 .. 2^22 - 1; never 0: a zeroed scratch block carries no valid tag
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(&st_next[6], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next iteration's live-sample counter
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += G) {
+        if (c != blockIdx.x) __syncthreads();  // wave_cnt is read by thread 0 of the previous round
+        composite_chunk<true>(c, n_alive, n_step, T_thresh, rays_in, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts,
+                              wave_cnt, tag);
+    }
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += G) {
+        __syncthreads();  // the reduction arrays of compact_chunk are reused; all of this workgroup's counts are on their way
+        compact_chunk<MARCH, true>(c, n_chunks, st, st_next, N, max_steps, rays_in, rays_out, block_counts, block_live, stats, m,
+                                   close_frame, iter, tag);
+    }
+    // every workgroup has read the epoch before it stored its first count, and nobody gets here before all counts are in
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[RN_HEAD_ST_BARRIER] = (int32_t)(epoch + 1u);
 }
 
 // Was the loop over after the iterations the caller enqueued?  (`st` = the state bank the NEXT iteration would read.)
@@ -1331,16 +1427,30 @@ int rn_head_iterate_ex(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_g
         // st[3] slots, skipping the dead ones by their deltas
         run_fused(h->xyzs, h->dirs, h->deltas, h->N, h->live_slots ? st + 6 : st + 3, grid_xyz, grid_amb, packed, bias, h->bound,
                   h->sigmas, h->rgbs, nullptr, mlp_dtype, s, h->live_slots);
-        hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
-                           h->deltas, h->weights_sum, h->depth, h->image, h->block_counts, st_next);
         const MarchArgs m{h->rays_t, h->rays_o, h->rays_d, h->fars, h->bound, h->dt_gamma, h->cascade, h->grid_size, h->bitfield,
                           h->xyzs, h->dirs, h->deltas, block_live[(it + 1) & 1u], h->live_slots};
-        if (it + 1 < first_iter + n_iters)
+        const bool march_next = it + 1 < first_iter + n_iters;
+        const uint32_t close = (!march_next && (flags & RN_LOOP_CLOSE_FRAME)) ? 1u : 0u;
+        if (flags & RN_LOOP_COOP) {  // compositor + compaction (+ next march) behind one launch (k_head_step)
+            const dim3 cgrid(rgrid.x < kStepGrid ? rgrid.x : kStepGrid);
+            if (march_next)
+                hipLaunchKernelGGL(k_head_step<true>, cgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, h->T_thresh, alive, alive_next,
+                                   h->rays_t, h->sigmas, h->rgbs, h->deltas, h->weights_sum, h->depth, h->image, h->block_counts,
+                                   block_live[it & 1u], h->state, m, 0u, it);
+            else
+                hipLaunchKernelGGL(k_head_step<false>, cgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, h->T_thresh, alive, alive_next,
+                                   h->rays_t, h->sigmas, h->rgbs, h->deltas, h->weights_sum, h->depth, h->image, h->block_counts,
+                                   block_live[it & 1u], h->state, m, close, it);
+            continue;
+        }
+        hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
+                           h->deltas, h->weights_sum, h->depth, h->image, h->block_counts, st_next);
+        if (march_next)
             hipLaunchKernelGGL(k_head_compact<true>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
                                h->block_counts, block_live[it & 1u], h->state, m, 0u, it);
         else
             hipLaunchKernelGGL(k_head_compact<false>, rgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, alive, alive_next,
-                               h->block_counts, block_live[it & 1u], h->state, m, (flags & RN_LOOP_CLOSE_FRAME) ? 1u : 0u, it);
+                               h->block_counts, block_live[it & 1u], h->state, m, close, it);
     }
     return check_launch("head_iterate");
 }

@@ -52,6 +52,7 @@ class HeadT(C.Structure):
 RN_HEAD_STATE_INTS = 64
 ST_HIST = 32
 ST_UNFINISHED = 19
+ST_STALLED = 22
 ST_ACTIVE, ST_ITERS, ST_LIVE, ST_SLOTS = 4, 16, 17, 18
 
 _SIGS = {
@@ -84,7 +85,7 @@ _lib.rn_nerf_packed_floats.restype = C.c_size_t
 _lib.rn_nerf_packed_floats_h16.restype = C.c_size_t
 _lib.rn_nerf_packed_floats_split.restype = C.c_size_t
 RN_F32_SPLIT = 2
-RN_LOOP_FIRST_MARCHED, RN_LOOP_CLOSE_FRAME = 1, 2
+RN_LOOP_FIRST_MARCHED, RN_LOOP_CLOSE_FRAME, RN_LOOP_COOP = 1, 2, 4
 _lib.rn_nerf_bias_floats.restype = C.c_size_t
 _lib.rn_torso_packed_floats.restype = C.c_size_t
 
@@ -205,7 +206,7 @@ class FusedState:
         self.rgbs = torch.empty(N, 3, dtype=f32, device=d)
         self.state = torch.zeros(RN_HEAD_STATE_INTS, dtype=i32, device=d)
         self.stats_prev = [0, 0, 0]
-        self.block_counts = torch.empty(3 * ((N + 255) // 256 + 1), dtype=i32, device=d)
+        self.block_counts = torch.zeros(3 * ((N + 255) // 256 + 1), dtype=i32, device=d)
         self.live_slots = torch.empty(N, dtype=i32, device=d)   # live-sample list of the iteration in flight
         self._N = N
 
@@ -302,6 +303,21 @@ def loop_history(model, n):
 def unfinished_frames(model):
     """Frames (cumulative) whose loop was cut short by a speculative iteration count (set_loop_hint); synchronises."""
     return sum(int(st.state[ST_UNFINISHED].item()) for st in _all_states(model))
+
+
+def stalled_workgroups(model):
+    """Workgroups (cumulative) that gave up at the in-launch barrier of the one-launch loop step (RN_LOOP_COOP); must be 0 --
+    a frame rendered while this moved is invalid.  Synchronises."""
+    return sum(int(st.state[ST_STALLED].item()) for st in _all_states(model))
+
+
+def loop_flags(model):
+    """Flags of rn_head_iterate_ex for this model: `opt.loop_launch` = "split" (default: a launch each for the compositor and
+    for compaction + next march, 3 launches per iteration) or "coop" (both in one launch with a grid-wide barrier inside, 2
+    launches per iteration; measured 2 % SLOWER on MI355X -- the barrier costs more than the kernel boundary it replaces,
+    DESIGN.md section 3 -- and limited to three streams per device, see RN_LOOP_COOP in radnerf_fused.h)."""
+    coop = getattr(model.opt, "loop_launch", "split") == "coop"
+    return RN_LOOP_COOP if coop else 0
 
 
 def set_loop_hint(model, iterations):
@@ -461,7 +477,7 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
         else:
             hip.call("rn_frame_begin", C.byref(h), None, 0.0, 0.0, 0.0, 0.0, 0, s)
         hip.call("rn_head_iterate_ex", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias), 0, n_iters,
-                 st.mlp_dtype, RN_LOOP_FIRST_MARCHED | RN_LOOP_CLOSE_FRAME, s)
+                 st.mlp_dtype, RN_LOOP_FIRST_MARCHED | RN_LOOP_CLOSE_FRAME | loop_flags(model), s)
     else:
         if ray_source is not None:
             pose, (fx, fy, cx, cy), W = ray_source
@@ -470,16 +486,16 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
                      hip.ptr(rays_d), s)
         hip.call("rn_head_begin", C.byref(h), s)
         if shard is None:
-            hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias), 0,
-                     n_iters, st.mlp_dtype, s)
+            hip.call("rn_head_iterate_ex", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias), 0,
+                     n_iters, st.mlp_dtype, loop_flags(model), s)
         else:
             # This call renders a shard of a frame (tile-parallel): the step schedule must be the whole frame's, so the
             # live-ray counts are summed over the ranks between iterations -- still without the host reading anything.
             group, n_total = shard
             total = torch.empty(1, dtype=torch.int32, device=dev)
             for it in range(n_iters):
-                hip.call("rn_head_iterate", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias),
-                         it, 1, st.mlp_dtype, s)
+                hip.call("rn_head_iterate_ex", C.byref(h), C.byref(st.gx), C.byref(st.gw), hip.ptr(st.packed), hip.ptr(bias),
+                         it, 1, st.mlp_dtype, loop_flags(model), s)
                 bank = ((it + 1) & 1) * 8
                 total.copy_(st.state[bank:bank + 1])
                 group.all_reduce(total)

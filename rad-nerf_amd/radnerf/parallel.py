@@ -54,6 +54,12 @@ class _Bookkeeping:
         m = self.scene.model
         cur = fused.loop_counters(m)                # synchronises; finish() is a synchronisation point anyway
         unfinished = fused.unfinished_frames(m)
+        stalled = fused.stalled_workgroups(m)
+        if stalled != getattr(self, "_stalled", 0):     # the in-launch barrier of the one-launch loop step timed out: never expected
+            self._stalled = stalled
+            m.opt.loop_launch = "split"
+            raise RuntimeError(f"{stalled} workgroup(s) gave up at the loop step's grid barrier (RN_LOOP_COOP); the frames since the "
+                               "last finish() are invalid -- switched to opt.loop_launch = 'split'")
         prev, self._counters = self._counters, (cur, unfinished)
         if cur is None or not self._frames_since_finish:
             return
@@ -144,6 +150,8 @@ class FrameParallelRenderer(_Bookkeeping):
         # frame's latency gets longer.
         self.n_streams = max(1, int(streams)) if getattr(scene.opt, "engine", "ops") == "fused" and scene.device.type == "cuda" else 1
         self._streams = [torch.cuda.Stream(device=scene.device) for _ in range(self.n_streams)] if self.n_streams > 1 else None
+        if self.n_streams > 3:       # the one-launch loop step needs its workgroups co-resident: at most three such streams (radnerf_fused.h)
+            scene.opt.loop_launch = "split"
         self._audio_ready = None
         self.audio_batch = max(0, int(audio_batch))
         self._ab = None                  # (first step, smoothed codes [K, dim], bias blocks [K, 192])

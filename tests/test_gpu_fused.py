@@ -457,6 +457,29 @@ def test_merged_frame_kernels_change_no_pixel(hiplib, mlp):
     assert fused.unfinished_frames(a.model) == 0 and fused._state(a.model).state[[6, 14]].tolist() == [0, 0]
 
 
+@pytest.mark.parametrize("size,kernels", [(96, "merged"), (96, "separate"), (512, "merged")])
+def test_one_launch_loop_step_changes_no_pixel(hiplib, size, kernels):
+    """opt.loop_launch = "coop" (compositor + compaction + next march of an iteration in one launch with a grid-wide
+    barrier inside, RN_LOOP_COOP) against the default "split" (a launch each for the compositor and the compaction): same frames, same
+    loop statistics, bit for bit; no workgroup ever gives up at the barrier.  512^2 = 1024 chunks of the alive list on 512
+    workgroups: the chunk loops of both phases are exercised."""
+    from radnerf import fused
+    a = _scene(size, "fused", frame_kernels=kernels, loop_launch="coop")
+    b = _scene(size, "fused", frame_kernels=kernels)
+    assert fused.loop_flags(a.model) == fused.RN_LOOP_COOP and fused.loop_flags(b.model) == 0
+    for i in range(3):
+        with torch.no_grad():
+            oa, ob = a.render(i, want_u8=True), b.render(i, want_u8=True)
+        for key in ("image", "image_u8", "weights_sum"):
+            if key in oa and key in ob:
+                assert torch.equal(oa[key], ob[key]), (i, key)
+        assert torch.equal(torch.nan_to_num(oa["depth"], nan=-1.0), torch.nan_to_num(ob["depth"], nan=-1.0))
+        assert dict(a.model.last_stats) == dict(b.model.last_stats)
+        assert torch.equal(fused.loop_history(a.model, 17), fused.loop_history(b.model, 17))
+    assert fused.stalled_workgroups(a.model) == 0 and fused.unfinished_frames(a.model) == 0
+    assert fused._state(a.model).state[[6, 14]].tolist() == [0, 0]
+
+
 def test_audio_batches_equal_the_per_frame_audio_path(hiplib):
     """FrameParallelRenderer(audio_batch=K): codes, smoothing recurrence and bias blocks of K frames in four launches; the
     frames must be the ones the per-frame path renders (same kernels on the same numbers)."""
