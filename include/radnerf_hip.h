@@ -99,6 +99,16 @@ int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t 
                         uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
                         float *deltas, int32_t *rays, int32_t *counter, const float *noises,
                         void *workspace, rn_stream_t stream);
+/* The same with the sample budget on the DEVICE: M is the capacity of xyzs / dirs / deltas (rows), *M_dev (<= M) the
+ * budget the drop rule `offset + n > M` uses (raymarching.cu:446-457).  A captured training step (hipGraph) can then
+ * follow the running-average budget of raymarching.py:226-229 without new shapes.  Rays dropped by the budget get
+ * rays[i].count = 0 (the compositors only know the capacity); all outputs equal those of rn_march_rays_train with
+ * M = *M_dev followed by the compositors with the same M. */
+int rn_march_rays_train_budget(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                               uint32_t M, const int32_t *M_dev, const float *nears, const float *fars,
+                               float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                               const float *noises, void *workspace, rn_stream_t stream);
 /* raymarching.h:15  march_rays_train_backward   (raymarching.cu:535-593) */
 int rn_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays,
                                  const float *deltas, uint32_t N, uint32_t M, float *grad_rays_o,

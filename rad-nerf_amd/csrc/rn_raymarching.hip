@@ -293,9 +293,11 @@ k_march_train_write(const float *__restrict__ rays_o, const float *__restrict__ 
                     const float *__restrict__ fars, const float *__restrict__ noises,
                     float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
                     int32_t *__restrict__ rays, int32_t *__restrict__ counter,
-                    const uint32_t *__restrict__ block_sums) {
+                    const uint32_t *__restrict__ block_sums, const int32_t *__restrict__ M_dev) {
     __shared__ uint32_t lds[kBlock / kWave];
     __shared__ uint32_t wave_tot[kBlock / kWave];
+    // M_dev (rn_march_rays_train_budget): the sample budget lives on the device and M is only the capacity of the buffers
+    if (M_dev) { const uint32_t b = (uint32_t)*M_dev; M = b < M ? b : M; }
     // samples reserved by all earlier blocks, on top of what the counter already holds (:446)
     uint32_t part = 0;
     for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) part += block_sums[b];
@@ -322,8 +324,11 @@ k_march_train_write(const float *__restrict__ rays_o, const float *__restrict__ 
         const uint32_t ray_index = counter1 + n;
         rays[ray_index * 3] = (int32_t)n;
         rays[ray_index * 3 + 1] = (int32_t)point_index;
-        rays[ray_index * 3 + 2] = (int32_t)num_steps;
-        if (num_steps != 0 && point_index + num_steps <= M) {
+        // a ray beyond the budget keeps its count in the reference (the compositor repeats the test with the same M); with a
+        // device-side budget the compositor only knows the capacity, so the ray is marked empty here -- same outputs
+        const bool fits = point_index + num_steps <= M;
+        rays[ray_index * 3 + 2] = (M_dev && !fits) ? 0 : (int32_t)num_steps;
+        if (num_steps != 0 && fits) {
             Dda s;
             s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid, fars[n]);
             float t = nears[n];
@@ -506,11 +511,11 @@ int rn_morton3D_dilation(const float *grid, uint32_t C, uint32_t H, float *grid_
 
 size_t rn_march_rays_train_workspace(uint32_t N) { return (size_t)(div_up(N, kBlock) + 1) * sizeof(uint32_t); }
 
-int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
-                        float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                        const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                        int32_t *rays, int32_t *counter, const float *noises, void *workspace,
-                        rn_stream_t stream) {
+int rn_march_rays_train_budget(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                               const int32_t *M_dev, const float *nears, const float *fars, float *xyzs, float *dirs,
+                               float *deltas, int32_t *rays, int32_t *counter, const float *noises, void *workspace,
+                               rn_stream_t stream) {
     if (N == 0) return RN_OK;
     RN_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises,
                "march_rays_train: null pointer");
@@ -522,10 +527,19 @@ int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t 
                        bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, rays, block_sums);
     hipLaunchKernelGGL(k_march_train_write, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, grid,
                        bound, dt_gamma, max_steps, N, C, H, M, nears, fars, noises, xyzs, dirs, deltas, rays, counter,
-                       block_sums);
+                       block_sums, M_dev);
     hipLaunchKernelGGL(k_march_train_counter, dim3(1), dim3(kBlock), 0, as_stream(stream), counter, block_sums,
                        blocks, N);
     return check_launch("march_rays_train");
+}
+
+int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                        float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                        const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                        int32_t *rays, int32_t *counter, const float *noises, void *workspace,
+                        rn_stream_t stream) {
+    return rn_march_rays_train_budget(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nullptr, nears, fars, xyzs, dirs,
+                                      deltas, rays, counter, noises, workspace, stream);
 }
 
 int rn_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays,

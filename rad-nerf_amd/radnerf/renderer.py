@@ -180,9 +180,16 @@ class NeRFRenderer(nn.Module):
             counter = self.step_counter[self.local_step % 16]
         counter.zero_()
         self.local_step += 1
-        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
-                                                                force_all_rays, dt_gamma, max_steps)
+        budget = getattr(self, "_sample_budget", None)             # (device int32 budget, row capacity): see radnerf/train.py
+        if budget is not None and not force_all_rays and self.mean_count > 0:
+            from raymarching.ops import march_rays_train_budget
+            xyzs, dirs, deltas, rays = march_rays_train_budget(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                               self.grid_size, nears, fars, counter, budget[0], budget[1], perturb,
+                                                               dt_gamma, max_steps)
+        else:
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                    force_all_rays, dt_gamma, max_steps)
         sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
         weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(self.density_scale * sigmas, rgbs,
                                                                                    ambient.abs().sum(-1), deltas, rays)

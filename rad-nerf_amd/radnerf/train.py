@@ -113,19 +113,25 @@ class GraphedTrainer(Trainer):
     fused Adam update are ~320 launches whose enqueue costs the host more than the GPU needs to run them; replaying them as
     one graph makes the step GPU-bound and its duration repeatable.
 
-    What stays outside the graph: the occupancy refresh every `update_extra_interval` steps (it changes `mean_count`, the
-    marcher's sample budget, i.e. the shapes: the graph is captured again after every refresh, into the same memory pool),
-    the batch (copied into the graph's static input buffers), the ring of per-step sample counters (the captured step
-    counts into one static pair, copied to the ring afterwards) and the first window, whose marcher reads back its sample
-    count (raymarching.py:249-255) and therefore runs eagerly.  Same arithmetic as Trainer.step."""
+    What stays outside the graph: the occupancy refresh every `update_extra_interval` steps, the batch (copied into the
+    graph's static input buffers), the ring of per-step sample counters (the captured step counts into one static pair,
+    copied to the ring afterwards) and the first window, whose marcher reads back its sample count (raymarching.py:249-255)
+    and therefore runs eagerly.  The refresh changes `mean_count`, the marcher's sample budget M (raymarching.py:226-229): the
+    graph is captured for a row CAPACITY (the budget rounded up to a multiple of `capacity_step`, kept while the budget stays
+    within it) and the budget itself is a device scalar the marcher reads (rn_march_rays_train_budget), so a refresh changes a
+    number, not the graph; rows between budget and capacity stay zero and belong to no ray.  The graph is captured again only
+    when the budget leaves the capacity window (or the batch shape changes).  Same arithmetic as Trainer.step."""
 
-    def __init__(self, model, opt, **kw):
+    def __init__(self, model, opt, capacity_step=4096, **kw):
         super().__init__(model, opt, capturable=True, **kw)
+        self.capacity_step = int(capacity_step)
+        self._capacity = 0
         self._graph = self._static = self._loss = self._key = None
         self._pool = None
         dev = next(model.parameters()).device
         self._amb_weight = torch.zeros((), dtype=torch.float32, device=dev)
         self._counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._budget = torch.zeros(1, dtype=torch.int32, device=dev)
         self.captures = self.replays = 0
 
     def _capture(self, data, key):
@@ -142,6 +148,7 @@ class GraphedTrainer(Trainer):
         g = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         m._static_counter = self._counter                     # renderer._head_training counts into this pair while captured
+        m._sample_budget = (self._budget, self._capacity)
         try:
             with torch.cuda.graph(g, pool=self._pool):
                 _, _, loss = train_step(m, self._static, self.opt, amb_weight=self._amb_weight)
@@ -149,6 +156,7 @@ class GraphedTrainer(Trainer):
                 self.optimizer.step()
         finally:
             m._static_counter = None
+            m._sample_budget = None
         m.local_step -= 1                                     # the capture pass went through the Python bookkeeping once
         self._graph, self._loss, self._key = g, loss, key
         del old
@@ -167,7 +175,13 @@ class GraphedTrainer(Trainer):
             loss.backward()
             self.optimizer.step()
             return loss.detach()
-        key = (int(m.mean_count), tuple(data["rays_o"].shape))
+        budget = int(m.mean_count)
+        budget += 128 - budget % 128                                     # raymarching.py:226-229 (align = 128)
+        step = self.capacity_step
+        if not (budget <= self._capacity <= budget + 2 * step):         # keep the capacity while the budget stays inside its window
+            self._capacity = -(-(budget + step // 4) // step) * step
+        self._budget.fill_(budget)
+        key = (self._capacity, tuple(data["rays_o"].shape))
         if self._graph is None or key != self._key:
             self._capture(data, key)
         for k, v in data.items():

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "rn_morton3D_dilation": [_ptr, _u32, _u32, _ptr, _ptr],
     "rn_march_rays_train": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr,
                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_march_rays_train_budget": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                   _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_march_rays_train_backward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_composite_rays_train_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr,
                                         _ptr],

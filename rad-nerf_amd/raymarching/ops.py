@@ -183,6 +183,44 @@ class _march_rays_train(Function):
 march_rays_train = _march_rays_train.apply
 
 
+class _march_rays_train_budget(Function):
+    """march_rays_train with the running-average sample budget ON THE DEVICE (not in the reference's surface; the captured
+    training step of radnerf/train.py uses it): `capacity` rows are allocated, `budget` (int32 device scalar <= capacity,
+    already aligned as raymarching.py:226-229 does) is what the drop rule compares with.  Same xyzs / dirs / deltas rows
+    and compositor outputs as march_rays_train(mean_count = budget); rows past the budget stay zero."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=_f32)
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, budget, capacity, perturb=False,
+                dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o, rays_d)
+        density_bitfield = hip.dev(density_bitfield).contiguous()
+        device = rays_o.device
+        N, M = rays_o.shape[0], int(capacity)
+        xyzs, dirs, deltas = _sample_buffers(M, device)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=device)
+        noises = torch.rand(N, dtype=_f32, device=device) if perturb else torch.zeros(N, dtype=_f32, device=device)
+        ws = hip.workspace(hip.workspace_bytes("rn_march_rays_train_workspace", N), device)
+        nears, fars = nears.contiguous(), fars.contiguous()
+        hip.call("rn_march_rays_train_budget", hip.ptr(rays_o, _f32), hip.ptr(rays_d, _f32), hip.ptr(density_bitfield, torch.uint8),
+                 float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), M, hip.ptr(budget, torch.int32), hip.ptr(nears, _f32),
+                 hip.ptr(fars, _f32), hip.ptr(xyzs), hip.ptr(dirs), hip.ptr(deltas), hip.ptr(rays), hip.ptr(step_counter, torch.int32),
+                 hip.ptr(noises), hip.ptr(ws), hip.stream())
+        ctx.save_for_backward(rays, deltas)
+        return xyzs, dirs, deltas, rays
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_xyzs, grad_dirs, grad_deltas, grad_rays):
+        return _march_rays_train.backward(ctx, grad_xyzs, grad_dirs, grad_deltas, grad_rays)[:14]
+
+
+def march_rays_train_budget(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, budget, capacity, perturb=False,
+                            dt_gamma=0, max_steps=1024):
+    return _march_rays_train_budget.apply(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, budget, capacity,
+                                          perturb, dt_gamma, max_steps)
+
+
 class _composite_rays_train(Function):
     # raymarching/raymarching.py:284-342
     @staticmethod

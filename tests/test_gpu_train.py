@@ -220,3 +220,67 @@ def test_graphed_trainer_replays_the_step_and_learns(hiplib):
     assert all(np.isfinite(losses)) and after < 0.5 * before, (before, after)
     assert trainer.replays == 36 and trainer.captures == 1
     assert int(m.step_counter[:, 0].max()) > 0 and m.local_step == 4 + 36 + 2   # +2: the two probes
+
+
+@pytest.mark.parametrize("budget_frac", [1.3, 0.6])
+def test_device_budget_marcher_equals_the_host_budget_marcher(hiplib, budget_frac):
+    """rn_march_rays_train_budget (budget = device scalar, capacity = buffer rows) against march_rays_train(mean_count =
+    budget): identical sample rows, counters and compositor outputs -- with a budget every ray fits in, and with one that
+    drops the tail rays (raymarching.cu:446-457)."""
+    import raymarching
+    from raymarching.ops import march_rays_train_budget
+    scene = _scene(64)
+    m, f = scene.model, scene.frame(0)
+    o, d = f["rays_o"].reshape(-1, 3).contiguous(), f["rays_d"].reshape(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, m.aabb_train, m.min_near)
+    args = (o, d, m.bound, m.density_bitfield, m.cascade, m.grid_size, nears, fars)
+    c0 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    raymarching.march_rays_train(*args, c0, -1, False, 128, True, scene.opt.dt_gamma, scene.opt.max_steps)
+    total = int(c0[0].item())
+    budget = int(total * budget_frac)
+    budget += 128 - budget % 128
+    c1, c2 = torch.zeros_like(c0), torch.zeros_like(c0)
+    x1, d1, dl1, r1 = raymarching.march_rays_train(*args, c1, budget - 128, False, 128, False, scene.opt.dt_gamma, scene.opt.max_steps)
+    assert x1.shape[0] == budget
+    cap = budget + 3000
+    x2, d2, dl2, r2 = march_rays_train_budget(*args, c2, torch.tensor([budget], dtype=torch.int32, device="cuda"), cap, False,
+                                              scene.opt.dt_gamma, scene.opt.max_steps)
+    assert x2.shape[0] == cap and torch.equal(c1, c2)
+    assert torch.equal(x1, x2[:budget]) and torch.equal(d1, d2[:budget]) and torch.equal(dl1, dl2[:budget])
+    assert not x2[budget:].any() and not dl2[budget:].any()
+    dropped = (r1[:, 1] + r1[:, 2]) > budget
+    assert bool(dropped.any()) == (budget_frac < 1)
+    assert torch.equal(r1[~dropped], r2[~dropped]) and torch.equal(r1[dropped][:, :2], r2[dropped][:, :2]) and not r2[dropped][:, 2].any()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sig1, rgb1, amb1 = (torch.rand(budget, device="cuda", generator=g) * 4, torch.rand(budget, 3, device="cuda", generator=g),
+                        torch.rand(budget, device="cuda", generator=g))
+    pad = lambda t: torch.cat([t, torch.rand(cap - budget, *t.shape[1:], device="cuda", generator=g)])   # rows no ray owns: anything
+    out1 = raymarching.composite_rays_train(sig1, rgb1, amb1, dl1, r1)
+    out2 = raymarching.composite_rays_train(pad(sig1), pad(rgb1), pad(amb1), dl2, r2)
+    for a, b in zip(out1, out2):
+        assert torch.equal(a, b)
+
+
+def test_graphed_trainer_keeps_its_graph_when_the_budget_moves(hiplib):
+    """The sample budget is a device scalar of the captured step: mean_count moving inside the capacity window costs no capture,
+    leaving it costs one."""
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream
+    scene = _scene(64, torso=False, smooth_lips=False)
+    stream = SyntheticTrainStream(scene, n_rays=2048)
+    m = scene.model
+    trainer = GraphedTrainer(m, scene.opt, update_extra_interval=0, capacity_step=2048)
+    for _ in range(3):
+        trainer.step(stream.batch())
+    base = int(m.step_counter[:3, 0].float().mean().item())
+    m.mean_count = base
+    trainer.step(stream.batch())
+    cap = trainer._capacity
+    assert trainer.captures == 1 and cap % 2048 == 0 and cap >= base
+    for mc in (base + 200, base - 300, base + 100):
+        m.mean_count = mc
+        loss = trainer.step(stream.batch())
+        assert int(trainer._budget.item()) == mc + 128 - mc % 128 and int(m.step_counter[(m.local_step - 1) % 16, 0]) > 0
+    assert trainer.captures == 1 and trainer._capacity == cap and np.isfinite(float(loss))
+    m.mean_count = cap + 500                    # leaves the window
+    trainer.step(stream.batch())
+    assert trainer.captures == 2 and trainer._capacity > cap
