@@ -294,6 +294,30 @@ int rn_audio_smooth_seq(const float *enc, uint32_t n, uint32_t dim, float lambda
 int rn_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
                 float *rays_d, rn_stream_t stream);
 
+/* ---- the per-sample MLPs in training --------------------------------------------------------
+ * nerf/network.py:69-88 (`MLP`: bias-free nn.Linear stack, ReLU between layers) with its autograd, for the shapes of the
+ * path: hidden width 64, n_layers 2 or 3, in_dim <= 96, out_dim <= 4 (narrow) or 64 .. 68 (64 wide rows preceded by
+ * out_dim - 64 narrow ones, as sigma_net's [sigma | geo_feat]).  x and grad_x are row-major [M, in_pad] with in_pad =
+ * in_dim rounded up to a multiple of 4 (pad columns of x are read: keep them zero); out / grad_out are [M, out_dim].
+ * Hidden activations h0 (h1: 3 layers) and pre-activation gradients dz0 (dz1) are opaque tile buffers of
+ * rn_mlp64_tile_floats(M) floats each, written by forward / backward and read by backward / weight_grads.  `image` holds
+ * rn_mlp64_image_floats() floats (16-byte aligned) and is rebuilt by rn_mlp64_pack whenever a weight changes (w0 [64,in_dim],
+ * w1 [64,64] (3 layers, else NULL), w_last [out_dim,64]: the nn.Linear weights).  Weight gradients are written (not
+ * accumulated) in the nn.Linear layout; `workspace` needs rn_mlp64_wgrad_workspace(n_layers) bytes.  fp32 MFMA throughout:
+ * equal to torch up to summation order. */
+size_t rn_mlp64_image_floats(uint32_t in_dim, uint32_t out_dim, uint32_t n_layers);
+size_t rn_mlp64_tile_floats(uint32_t M);
+size_t rn_mlp64_wgrad_workspace(uint32_t n_layers);
+int rn_mlp64_pack(const float *w0, const float *w1, const float *w_last, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
+                  float *image, rn_stream_t stream);
+int rn_mlp64_forward(const float *x, uint32_t M, const float *image, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers, float *out,
+                     float *h0, float *h1, rn_stream_t stream);
+int rn_mlp64_backward(const float *grad_out, uint32_t M, const float *image, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
+                      const float *h0, const float *h1, float *grad_x, float *dz0, float *dz1, rn_stream_t stream);
+int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
+                          const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, float *gw1,
+                          float *gw_last, void *workspace, rn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

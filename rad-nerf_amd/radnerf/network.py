@@ -88,6 +88,20 @@ class _SkinnyLinear(torch.autograd.Function):
         return gx, gw
 
 
+_MLP_KERNELS = []
+
+
+def _mlp_kernels():
+    """radnerf.mlp_train (needs the HIP library), or None when RN_MLP_TRAIN=torch selects the nn.Linear path."""
+    import os
+    if os.environ.get("RN_MLP_TRAIN", "hip") == "torch":
+        return None
+    if not _MLP_KERNELS:
+        from . import mlp_train
+        _MLP_KERNELS.append(mlp_train)
+    return _MLP_KERNELS[0]
+
+
 class MLP(nn.Module):
     """Bias-free Linear stack with ReLU between layers (nerf/network.py:69-88)."""
 
@@ -99,7 +113,14 @@ class MLP(nn.Module):
             for l in range(num_layers)])
 
     def forward(self, x):
-        skinny = x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.shape[0] >= 4096 and x.dtype == torch.float32
+        training_shape = x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.dtype == torch.float32 and \
+            not torch.is_autocast_enabled()
+        # training on the GPU: hand-written forward / backward kernels for the whole stack (radnerf/mlp_train.py), unless
+        # RN_MLP_TRAIN=torch asks for the nn.Linear path (the parity tests compare the two)
+        if training_shape and x.shape[0] >= 1024 and _mlp_kernels() is not None and \
+                _mlp_kernels().supported(self.dim_in, self.dim_out, self.dim_hidden, self.num_layers):
+            return _mlp_kernels().fused_mlp(x, [layer.weight for layer in self.net])
+        skinny = training_shape and x.shape[0] >= 4096
         for l, layer in enumerate(self.net):
             x = _SkinnyLinear.apply(x, layer.weight) if skinny and not torch.is_autocast_enabled() else layer(x)
             if l != self.num_layers - 1:
