@@ -271,6 +271,16 @@ typedef struct {
  * allocated like every buffer; may be NULL when has_att == 0). */
 int rn_audio_encode_windows(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, float *workspace,
                             rn_stream_t stream);
+/* Backward of rn_audio_encode_windows for the training step: given grad_enc [n, dim_aud] (and `codes`, the forward's
+ * workspace with the per-frame codes), ADDS the gradients of every AudioNet / AudioAttNet parameter to the buffers of
+ * `grads` (same shapes as the weights; zero them first for a plain gradient).  grad_codes: n * 8 * dim_aud floats of scratch
+ * (has_att).  The input features receive no gradient (they are data). */
+typedef struct {
+    float *conv_w[4], *conv_b[4], *fc_w[2], *fc_b[2], *att_conv_w[5], *att_conv_b[5], *att_fc_w, *att_fc_b;
+} rn_audio_grads_t;
+int rn_audio_encode_windows_backward(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes,
+                                     const float *grad_enc, const rn_audio_grads_t *grads, float *grad_codes,
+                                     rn_stream_t stream);
 /* The same for n consecutive frames (first + i) mod T of a feature stream feats [T, dim_in, 16]: the windows are cut on
  * the device exactly as get_audio_features(att_mode=2) does (nerf/utils.py:56-72: frames index-4 .. index+3, zero rows
  * outside the stream).  Needs T >= 8 and has_att. */

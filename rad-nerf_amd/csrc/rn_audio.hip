@@ -226,6 +226,198 @@ __global__ void k_audio_smooth(const float *__restrict__ enc, uint32_t n, uint32
     state[i] = s;
 }
 
+// ==========================================================================================================
+// Backward of encode_audio for the training step (nerf/utils.py:718-806 trains audio_net / audio_att_net with lr_net):
+// the same two-kernel shape as the forward.  Each workgroup recomputes its forward with every layer's output kept in LDS,
+// then walks the layers backwards; weight and bias gradients are ADDED to the caller's buffers with atomics (8 frames
+// share AudioNet's weights).  ~50 torch / MIOpen launches (naive conv kernels of 7 - 20 us each) become two.
+struct AudioG {
+    float *conv_w[4], *conv_b[4], *fc_w[2], *fc_b[2], *att_conv_w[5], *att_conv_b[5], *att_fc_w, *att_fc_b;
+};
+
+__device__ __forceinline__ float leaky_grad(float y) { return y > 0.0f ? 1.0f : 0.02f; }  // y = leaky(z) has the sign of z
+
+__device__ __forceinline__ void stage_weights(float *dst, const float *__restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += kAudioThreads) dst[i] = src[i];
+}
+
+// Backward of conv3 (+ LeakyReLU): x [cin][len_in] -> y [cout][len_out].  dy is turned into dz in place; gw / gb receive
+// atomicAdds; dx (nullable) [cin][len_in] is written.  Ends with a barrier.
+__device__ __forceinline__ void conv3_bwd(const float *x, const float *y, float *dy, const float *w, float *__restrict__ gw,
+                                          float *__restrict__ gb, float *dx, int cin, int cout, int len_in, int stride) {
+    const int len_out = (len_in - 1) / stride + 1;
+    for (int o = threadIdx.x; o < cout * len_out; o += kAudioThreads) dy[o] *= leaky_grad(y[o]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cout * cin * 3; e += kAudioThreads) {
+        const int k = e % 3, ci = (e / 3) % cin, co = e / (3 * cin);
+        float acc = 0.0f;
+        for (int pos = 0; pos < len_out; pos++) {
+            const int p = pos * stride - 1 + k;
+            if (p >= 0 && p < len_in) acc += dy[co * len_out + pos] * x[ci * len_in + p];
+        }
+        atomicAdd(gw + e, acc);
+    }
+    for (int co = threadIdx.x; co < cout; co += kAudioThreads) {
+        float acc = 0.0f;
+        for (int pos = 0; pos < len_out; pos++) acc += dy[co * len_out + pos];
+        atomicAdd(gb + co, acc);
+    }
+    if (dx) {
+        for (int e = threadIdx.x; e < cin * len_in; e += kAudioThreads) {
+            const int p = e % len_in, ci = e / len_in;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int q = p + 1 - k;  // = pos * stride
+                if (q < 0 || q % stride) continue;
+                const int pos = q / stride;
+                if (pos >= len_out) continue;
+                for (int co = 0; co < cout; co++) acc += w[(co * cin + ci) * 3 + k] * dy[co * len_out + pos];
+            }
+            dx[e] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+// Backward of linear(): y [dout] = act(W x + b).  dy -> dz in place (act), gw/gb atomics, dx written.  Ends with a barrier.
+__device__ __forceinline__ void linear_bwd(const float *x, const float *y, float *dy, const float *w, float *__restrict__ gw,
+                                           float *__restrict__ gb, float *dx, int din, int dout, bool act) {
+    if (act) {
+        for (int o = threadIdx.x; o < dout; o += kAudioThreads) dy[o] *= leaky_grad(y[o]);
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < dout * din; e += kAudioThreads) atomicAdd(gw + e, dy[e / din] * x[e % din]);
+    for (int o = threadIdx.x; o < dout; o += kAudioThreads) atomicAdd(gb + o, dy[o]);
+    if (dx) {
+        for (int k = threadIdx.x; k < din; k += kAudioThreads) {
+            float acc = 0.0f;
+            for (int r = 0; r < dout; r++) acc += w[r * din + k] * dy[r];
+            dx[k] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+// AudioAttNet backward, one window per workgroup: grad_enc [n][A] + codes [n][8][A] -> grad_codes [n][8][A]
+__global__ void __launch_bounds__(kAudioThreads) k_audio_attend_bwd(AudioW w, AudioG g, const float *__restrict__ codes_all,
+                                                                    const float *__restrict__ grad_enc, float *__restrict__ grad_codes) {
+    __shared__ float wts[64 * 16 * 3 + 16 * 8 * 3 + 8 * 4 * 3 + 4 * 2 * 3 + 2 * 1 * 3];
+    __shared__ float act[(64 + 16 + 8 + 4 + 2 + 1) * kSeq];   // a0 (= codes^T) .. a5 (scores)
+    __shared__ float grad[2][64 * kSeq];
+    __shared__ float codes[kSeq * 64], att[kSeq], logit_g[kSeq], genc[64];
+    const int A = (int)w.dim_aud;
+    const uint32_t win = blockIdx.x;
+    const int chans[6] = {A, 16, 8, 4, 2, 1};
+    int woff[6], aoff[7];
+    woff[0] = 0; aoff[0] = 0;
+    for (int l = 0; l < 5; l++) woff[l + 1] = woff[l] + chans[l + 1] * chans[l] * 3;
+    for (int l = 0; l < 6; l++) aoff[l + 1] = aoff[l] + chans[l] * kSeq;
+    for (int l = 0; l < 5; l++) stage_weights(wts + woff[l], w.att_conv_w[l], woff[l + 1] - woff[l]);
+    for (int i = threadIdx.x; i < kSeq * A; i += kAudioThreads) codes[i] = codes_all[(size_t)win * kSeq * A + i];
+    for (int i = threadIdx.x; i < A; i += kAudioThreads) genc[i] = grad_enc[(size_t)win * A + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * kSeq; i += kAudioThreads) act[i] = codes[(i % kSeq) * A + i / kSeq];
+    __syncthreads();
+    for (int l = 0; l < 5; l++) {   // forward, every layer kept
+        conv3(act + aoff[l], act + aoff[l + 1], wts + woff[l], w.att_conv_b[l], 1, chans[l], chans[l + 1], kSeq, 1);
+        __syncthreads();
+    }
+    const float *score = act + aoff[5];
+    if (threadIdx.x < kSeq) {
+        float acc = w.att_fc_b[threadIdx.x];
+        for (int k = 0; k < kSeq; k++) acc += w.att_fc_w[threadIdx.x * kSeq + k] * score[k];
+        att[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = att[0];
+        for (int t = 1; t < kSeq; t++) m = fmaxf(m, att[t]);
+        float e[kSeq], s = 0.0f;
+        for (int t = 0; t < kSeq; t++) { e[t] = expf(att[t] - m); s += e[t]; }
+        for (int t = 0; t < kSeq; t++) att[t] = e[t] / s;
+    }
+    __syncthreads();
+    // enc = sum_t att[t] codes[t]: d att[t] = <genc, codes[t]>; softmax backward -> d logits
+    if (threadIdx.x < kSeq) {
+        float acc = 0.0f;
+        for (int i = 0; i < A; i++) acc += genc[i] * codes[threadIdx.x * A + i];
+        logit_g[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float dot = 0.0f;
+        for (int t = 0; t < kSeq; t++) dot += att[t] * logit_g[t];
+        for (int t = 0; t < kSeq; t++) logit_g[t] = att[t] * (logit_g[t] - dot);
+    }
+    __syncthreads();
+    // attentionNet Linear(8, 8): logits = W score + b
+    float *ga = grad[0], *gb_ = grad[1];
+    if (threadIdx.x < kSeq * kSeq) atomicAdd(g.att_fc_w + threadIdx.x, logit_g[threadIdx.x / kSeq] * score[threadIdx.x % kSeq]);
+    if (threadIdx.x < kSeq) {
+        atomicAdd(g.att_fc_b + threadIdx.x, logit_g[threadIdx.x]);
+        float acc = 0.0f;
+        for (int t = 0; t < kSeq; t++) acc += w.att_fc_w[t * kSeq + threadIdx.x] * logit_g[t];
+        ga[threadIdx.x] = acc;    // d score
+    }
+    __syncthreads();
+    for (int l = 4; l >= 0; l--) {
+        conv3_bwd(act + aoff[l], act + aoff[l + 1], ga, wts + woff[l], g.att_conv_w[l], g.att_conv_b[l], gb_, chans[l], chans[l + 1],
+                  kSeq, 1);
+        float *t = ga; ga = gb_; gb_ = t;
+    }
+    // ga: d a0 [A][8]; codes enter twice: through a0 (permuted) and through the weighted sum
+    for (int i = threadIdx.x; i < kSeq * A; i += kAudioThreads) {
+        const int t = i / A, c = i % A;
+        grad_codes[(size_t)win * kSeq * A + i] = ga[c * kSeq + t] + att[t] * genc[c];
+    }
+}
+
+// AudioNet backward, one frame per workgroup: grad_codes [n * frames][A] -> weight gradients
+__global__ void __launch_bounds__(kAudioThreads) k_audio_frames_bwd(AudioW w, AudioG g, Source src, const float *__restrict__ grad_codes) {
+    __shared__ float wts[kMaxWeights];
+    __shared__ float x0[kMaxDimIn * kWin], y1[32 * 8], y2[32 * 4], y3[64 * 2], y4[64], y5[64];
+    __shared__ float ga[32 * 8], gb_[32 * 8];
+    const int frames = w.has_att ? kSeq : 1;
+    const int cin0 = (int)w.dim_in, A = (int)w.dim_aud;
+    const uint32_t win = blockIdx.x / frames, t = blockIdx.x % frames;
+    for (int i = threadIdx.x; i < cin0 * kWin; i += kAudioThreads) {
+        float v;
+        if (src.from_stream) {
+            const int centre = (int)((src.first + win) % src.T);
+            const int gidx = centre - 4 + (int)t;
+            v = (gidx >= 0 && gidx < (int)src.T) ? src.base[(size_t)gidx * cin0 * kWin + i] : 0.0f;
+        } else {
+            v = src.base[(size_t)blockIdx.x * cin0 * kWin + i];
+        }
+        x0[i] = v;
+    }
+    // forward with every layer kept (same helpers, same order of operations as k_audio_frames)
+    stage_weights(wts, w.conv_w[0], 32 * cin0 * 3); __syncthreads();
+    conv3(x0, y1, wts, w.conv_b[0], 1, cin0, 32, 16, 2); __syncthreads();
+    stage_weights(wts, w.conv_w[1], 32 * 32 * 3); __syncthreads();
+    conv3(y1, y2, wts, w.conv_b[1], 1, 32, 32, 8, 2); __syncthreads();
+    stage_weights(wts, w.conv_w[2], 64 * 32 * 3); __syncthreads();
+    conv3(y2, y3, wts, w.conv_b[2], 1, 32, 64, 4, 2); __syncthreads();
+    stage_weights(wts, w.conv_w[3], 64 * 64 * 3); __syncthreads();
+    conv3(y3, y4, wts, w.conv_b[3], 1, 64, 64, 2, 2); __syncthreads();
+    stage_weights(wts, w.fc_w[0], 64 * 64); __syncthreads();
+    linear(y4, y5, wts, w.fc_b[0], 1, 64, 64, true); __syncthreads();
+    // backward
+    for (int i = threadIdx.x; i < A; i += kAudioThreads) ga[i] = grad_codes[(size_t)blockIdx.x * A + i];
+    stage_weights(wts, w.fc_w[1], A * 64); __syncthreads();
+    linear_bwd(y5, nullptr, ga, wts, g.fc_w[1], g.fc_b[1], gb_, 64, A, false);
+    stage_weights(wts, w.fc_w[0], 64 * 64); __syncthreads();
+    linear_bwd(y4, y5, gb_, wts, g.fc_w[0], g.fc_b[0], ga, 64, 64, true);
+    stage_weights(wts, w.conv_w[3], 64 * 64 * 3); __syncthreads();
+    conv3_bwd(y3, y4, ga, wts, g.conv_w[3], g.conv_b[3], gb_, 64, 64, 2, 2);
+    stage_weights(wts, w.conv_w[2], 64 * 32 * 3); __syncthreads();
+    conv3_bwd(y2, y3, gb_, wts, g.conv_w[2], g.conv_b[2], ga, 32, 64, 4, 2);
+    stage_weights(wts, w.conv_w[1], 32 * 32 * 3); __syncthreads();
+    conv3_bwd(y1, y2, ga, wts, g.conv_w[1], g.conv_b[1], gb_, 32, 32, 8, 2);
+    conv3_bwd(x0, y1, gb_, wts, g.conv_w[0], g.conv_b[0], nullptr, cin0, 32, 16, 2);   // no dx: weights not needed
+}
+
 static int check_audio(const rn_audio_weights_t *w) {
     RN_REQUIRE(w, "audio: null weights");
     for (int l = 0; l < 4; l++) RN_REQUIRE(w->conv_w[l] && w->conv_b[l], "audio: null AudioNet conv weights");
@@ -283,6 +475,30 @@ int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint
     RN_REQUIRE(feats && enc, "audio_encode_stream: null pointer");
     RN_REQUIRE(w->has_att && T >= 8, "audio_encode_stream: needs the attention window (has_att) and a stream of >= 8 frames");
     return launch_audio(w, Source{feats, T, first, 1}, n, enc, workspace, as_stream(stream), "audio_encode_stream");
+}
+
+int rn_audio_encode_windows_backward(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes,
+                                     const float *grad_enc, const rn_audio_grads_t *grads, float *grad_codes, rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    if (int rc = check_audio(w)) return rc;
+    RN_REQUIRE(auds && grad_enc && grads, "audio_encode_windows_backward: null pointer");
+    AudioG g{};
+    for (int l = 0; l < 4; l++) { g.conv_w[l] = grads->conv_w[l]; g.conv_b[l] = grads->conv_b[l]; RN_REQUIRE(g.conv_w[l] && g.conv_b[l], "audio backward: null AudioNet gradient buffer"); }
+    for (int l = 0; l < 2; l++) { g.fc_w[l] = grads->fc_w[l]; g.fc_b[l] = grads->fc_b[l]; RN_REQUIRE(g.fc_w[l] && g.fc_b[l], "audio backward: null AudioNet gradient buffer"); }
+    const AudioW a = audio_w(w);
+    const Source src{auds, 0u, 0u, 0};
+    hipStream_t s = as_stream(stream);
+    if (!a.has_att) {
+        hipLaunchKernelGGL(k_audio_frames_bwd, dim3(n), dim3(kAudioThreads), 0, s, a, g, src, grad_enc);
+        return check_launch("audio_encode_windows_backward");
+    }
+    RN_REQUIRE(codes && grad_codes, "audio_encode_windows_backward: the forward's per-frame codes and n * 8 * dim_aud floats of scratch are required");
+    for (int l = 0; l < 5; l++) { g.att_conv_w[l] = grads->att_conv_w[l]; g.att_conv_b[l] = grads->att_conv_b[l]; RN_REQUIRE(g.att_conv_w[l] && g.att_conv_b[l], "audio backward: null AudioAttNet gradient buffer"); }
+    g.att_fc_w = grads->att_fc_w; g.att_fc_b = grads->att_fc_b;
+    RN_REQUIRE(g.att_fc_w && g.att_fc_b, "audio backward: null AudioAttNet gradient buffer");
+    hipLaunchKernelGGL(k_audio_attend_bwd, dim3(n), dim3(kAudioThreads), 0, s, a, g, codes, grad_enc, grad_codes);
+    hipLaunchKernelGGL(k_audio_frames_bwd, dim3(n * kSeq), dim3(kAudioThreads), 0, s, a, g, src, grad_codes);
+    return check_launch("audio_encode_windows_backward");
 }
 
 int rn_audio_smooth(const float *enc, uint32_t n, uint32_t dim, float lambda, float *state, int state_valid,

@@ -20,8 +20,14 @@ class AudioWeightsT(C.Structure):
                 ("dim_in", _u32), ("dim_aud", _u32), ("has_att", _u32)]
 
 
+class AudioGradsT(C.Structure):
+    _fields_ = [("conv_w", _ptr * 4), ("conv_b", _ptr * 4), ("fc_w", _ptr * 2), ("fc_b", _ptr * 2),
+                ("att_conv_w", _ptr * 5), ("att_conv_b", _ptr * 5), ("att_fc_w", _ptr), ("att_fc_b", _ptr)]
+
+
 _SIGS = {
     "rn_audio_encode_windows": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, _ptr],
+    "rn_audio_encode_windows_backward": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, C.POINTER(AudioGradsT), _ptr, _ptr],
     "rn_audio_encode_stream": [C.POINTER(AudioWeightsT), _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_audio_smooth": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr],
     "rn_audio_smooth_seq": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr, _ptr],
@@ -90,6 +96,76 @@ def encode_windows(model, auds):
     w, keep = _weights(model)
     hip.call("rn_audio_encode_windows", C.byref(w), hip.ptr(auds), n, hip.ptr(enc), hip.ptr(ws), hip.stream())
     return enc
+
+
+def _parameters(model):
+    """The audio nets' parameters in the order of the weight struct: 4 x (conv w, b), 2 x (fc w, b) [, 5 x (att conv w, b), att fc w, b]."""
+    ps = []
+    for c in (m for m in model.audio_net.encoder_conv if isinstance(m, torch.nn.Conv1d)):
+        ps += [c.weight, c.bias]
+    for f in (m for m in model.audio_net.encoder_fc1 if isinstance(m, torch.nn.Linear)):
+        ps += [f.weight, f.bias]
+    if model.att > 0:
+        for c in (m for m in model.audio_att_net.attentionConvNet if isinstance(m, torch.nn.Conv1d)):
+            ps += [c.weight, c.bias]
+        lin = model.audio_att_net.attentionNet[0]
+        ps += [lin.weight, lin.bias]
+    return ps
+
+
+class _EncodeWindows(torch.autograd.Function):
+    """encode_audio with gradients for the audio nets' parameters (the input features are data): forward = the two forward
+    kernels, backward = rn_audio_encode_windows_backward (two kernels) instead of ~100 torch / MIOpen launches."""
+
+    @staticmethod
+    def forward(ctx, model, auds, *params):
+        n = auds.shape[0]
+        enc = torch.empty(n, model.audio_dim, dtype=torch.float32, device=auds.device)
+        codes = torch.empty(n * 8, model.audio_dim, dtype=torch.float32, device=auds.device)
+        w, keep = _weights(model)
+        hip.call("rn_audio_encode_windows", C.byref(w), hip.ptr(auds), n, hip.ptr(enc), hip.ptr(codes), hip.stream())
+        ctx.model = model
+        ctx.save_for_backward(auds, codes)
+        return enc
+
+    @staticmethod
+    def backward(ctx, grad_enc):
+        model = ctx.model
+        auds, codes = ctx.saved_tensors
+        params = _parameters(model)
+        sizes = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=auds.device)      # one memset for all gradient buffers
+        views, at = [], 0
+        for p, k in zip(params, sizes):
+            views.append(flat[at:at + k].view(p.shape))
+            at += k
+        g = AudioGradsT()
+        it = iter(v.data_ptr() for v in views)
+        for i in range(4):
+            g.conv_w[i], g.conv_b[i] = next(it), next(it)
+        for i in range(2):
+            g.fc_w[i], g.fc_b[i] = next(it), next(it)
+        if model.att > 0:
+            for i in range(5):
+                g.att_conv_w[i], g.att_conv_b[i] = next(it), next(it)
+            g.att_fc_w, g.att_fc_b = next(it), next(it)
+        w, keep = _weights(model)
+        ge = grad_enc.contiguous().float()
+        scratch = torch.empty_like(codes)
+        hip.call("rn_audio_encode_windows_backward", C.byref(w), hip.ptr(auds), auds.shape[0], hip.ptr(codes), hip.ptr(ge), C.byref(g),
+                 hip.ptr(scratch), hip.stream())
+        return (None, None, *views)
+
+
+def encode_windows_train(model, auds):
+    """encode_windows, differentiable in the audio nets' parameters (training step)."""
+    if auds.dim() == 3:
+        auds = auds.unsqueeze(0)
+    auds = auds.contiguous().float()
+    frames = 8 if model.att > 0 else 1
+    if tuple(auds.shape[1:]) != (frames, model.audio_in_dim, 16):
+        raise RuntimeError(f"audio windows must be [n, {frames}, {model.audio_in_dim}, 16], got {tuple(auds.shape)}")
+    return _EncodeWindows.apply(model, auds, *_parameters(model))
 
 
 def encode_stream(model, feats, first, n):

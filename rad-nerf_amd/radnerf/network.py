@@ -89,6 +89,19 @@ class _SkinnyLinear(torch.autograd.Function):
 
 
 _MLP_KERNELS = []
+_AUDIO_KERNELS = []
+
+
+def _audio_kernels(model):
+    """radnerf.audio when its kernels cover the model's audio nets, or None (RN_AUDIO_TRAIN=torch: the nn.Module path)."""
+    import os
+    if os.environ.get("RN_AUDIO_TRAIN", "hip") == "torch":
+        return None
+    if not _AUDIO_KERNELS:
+        from . import audio
+        _AUDIO_KERNELS.append(audio)
+    a = _AUDIO_KERNELS[0]
+    return a if a.supported(model) and any(p.requires_grad for p in model.audio_net.parameters()) else None
 
 
 def _mlp_kernels():
@@ -182,6 +195,11 @@ class NeRFNetwork(NeRFRenderer):
             return None
         if self.emb:
             a = self.embedding(a).transpose(-1, -2).contiguous()
+        # training on the GPU: forward and backward of both audio nets as two kernels each (radnerf/audio.py) instead of
+        # ~150 launches of tiny convolutions; RN_AUDIO_TRAIN=torch keeps the nn.Module path (the parity test compares them)
+        if a.is_cuda and torch.is_grad_enabled() and not self.emb and a.dtype == torch.float32 and \
+                not torch.is_autocast_enabled() and _audio_kernels(self) is not None:
+            return _audio_kernels(self).encode_windows_train(self, a)
         enc_a = self.audio_net(a)
         if self.att > 0:
             enc_a = self.audio_att_net(enc_a.unsqueeze(0))

@@ -92,3 +92,28 @@ def test_frame_parallel_advance_uses_one_launch(hiplib):
         for s in range(3):                      # frames 2, 5, 8
             fpr.step(s)
     assert (seq.model.enc_a - par.model.enc_a).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("asr,att", [("cpierse/wav2vec2-large-xlsr-53-esperanto", 2), ("deepspeech", 2), ("other", 0)])
+def test_backward_kernels_match_torch_autograd(hiplib, monkeypatch, asr, att):
+    """rn_audio_encode_windows_backward (radnerf.audio.encode_windows_train, what NeRFNetwork.encode_audio uses under autograd on the
+    GPU) against torch autograd through the nn.Modules: every parameter gradient of AudioNet (+ AudioAttNet) within 1e-4 of its
+    largest magnitude (fp32 sums in a different order; the gradient of one code is the sum over 8 frames and 16 positions)."""
+    from radnerf.rays import get_audio_features
+    scene = _scene(asr_model=asr, att=att)
+    m = scene.model
+    m.train()
+    feats = torch.randn(24, m.audio_in_dim, 16, device="cuda") * 2
+    a = get_audio_features(feats, 2, 7) if att > 0 else torch.randn(1, m.audio_in_dim, 16, device="cuda")
+    gy = torch.randn(1, 64, device="cuda")
+    params = [p for mod in ([m.audio_net] + ([m.audio_att_net] if att > 0 else [])) for p in mod.parameters()]
+    grads = {}
+    for env in ("hip", "torch"):
+        monkeypatch.setenv("RN_AUDIO_TRAIN", env)
+        enc = m.encode_audio(a)
+        assert enc.shape == (1, 64) and enc.requires_grad
+        grads[env] = (enc.detach().clone(), torch.autograd.grad(enc, params, gy))
+    assert (grads["hip"][0] - grads["torch"][0]).abs().max().item() <= 2e-5 * max(1.0, grads["torch"][0].abs().max().item())
+    for p, g, r in zip(params, grads["hip"][1], grads["torch"][1]):
+        assert g.shape == r.shape
+        assert (g - r).abs().max().item() <= 1e-4 * max(float(r.abs().max()), 1e-3), (tuple(p.shape), float((g - r).abs().max()), float(r.abs().max()))
