@@ -328,6 +328,22 @@ int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uin
                           const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, float *gw1,
                           float *gw_last, void *workspace, rn_stream_t stream);
 
+/* ---- optimizer update of the training step ------------------------------------------------------------------------
+ * torch.optim.Adam as main.py:204 configures it (betas, eps; no weight decay, no amsgrad) for `count` tensors in ONE
+ * launch (+ a one-thread launch that advances *step and computes the bias corrections in double, as Python does):
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `tensors` is a HOST array (the pointers travel as kernel arguments, 48 tensors per launch); *step (device int32) counts
+ * the steps taken, corr is a 2-float device scratch.  Enqueue-only, capturable in a hipGraph. */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    uint32_t numel;
+    float lr;
+} rn_adam_tensor_t;
+int rn_adam_step(const rn_adam_tensor_t *tensors, uint32_t count, float beta1, float beta2, float eps, int32_t *step, float *corr,
+                 rn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,14 +11,112 @@ learning-rate schedule are outside the path (out of scope) and are not
 import torch
 
 
-def make_optimizer(model, lr=5e-3, lr_net=5e-4, fused=None, capturable=False):
+def make_optimizer(model, lr=5e-3, lr_net=5e-4, fused=None, capturable=False, kernel=None):
     """main.py:204; lr for the grid tables, lr_net for the MLPs / audio nets / individual codes.  On the GPU the update runs
-    as torch's fused Adam (one kernel per parameter group: the 49 MB table is read and written once per step instead of once
-    per foreach primitive); same arithmetic as the default implementation."""
+    as ONE kernel over all tensors (HipAdam; `kernel="torch"` or RN_ADAM=torch: torch's fused Adam, one launch per parameter
+    group) -- the 49 MB table is read and written once per step either way; same arithmetic as the default implementation."""
+    import os
+    on_gpu = next(model.parameters()).is_cuda
+    if kernel is None:
+        kernel = os.environ.get("RN_ADAM", "hip") if on_gpu else "torch"
+    if kernel == "hip" and on_gpu:
+        return HipAdam(model.get_params(lr, lr_net))
     if fused is None:
-        fused = next(model.parameters()).is_cuda
+        fused = on_gpu
     return torch.optim.Adam(model.get_params(lr, lr_net), betas=(0.9, 0.99), eps=1e-15, fused=bool(fused),
                             capturable=bool(capturable))
+
+
+class HipAdam:
+    """torch.optim.Adam(betas, eps, weight_decay=0) over the model's parameter groups with ONE update kernel for all
+    tensors (C ABI rn_adam_step, csrc/rn_train.hip) -- the table, its moments and its gradient stream through HBM once.
+    Same interface as far as Trainer needs it (param_groups, zero_grad, step, state_dict / load_state_dict in
+    torch.optim.Adam's format, so reference checkpoints carry over); the step counter lives on the device, so a step is
+    capturable in a hipGraph."""
+
+    def __init__(self, params, betas=(0.9, 0.99), eps=1e-15):
+        import ctypes as C
+        import radnerf_hip as hip
+        self._C, self._hip = C, hip
+
+        class AdamTensorT(C.Structure):
+            _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                        ("numel", C.c_uint32), ("lr", C.c_float)]
+        self._T = AdamTensorT
+        fn = hip._lib.rn_adam_step
+        fn.argtypes = [C.POINTER(AdamTensorT), C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn.restype = C.c_int
+        self.param_groups = []
+        for g in params:
+            g = dict(g)
+            g["params"] = [g["params"]] if torch.is_tensor(g["params"]) else list(g["params"])    # a bare tensor is one parameter
+            if g.get("weight_decay", 0):
+                raise ValueError("HipAdam: weight decay is not part of the reference's configuration (main.py:204) and not implemented")
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            self.param_groups.append(g)
+        self.betas, self.eps = betas, eps
+        dev = self.param_groups[0]["params"][0].device
+        self.state = {p: {"exp_avg": torch.zeros_like(p, memory_format=torch.contiguous_format),
+                          "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
+                      for g in self.param_groups for p in g["params"]}
+        self._step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._corr = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        entries, keep = [], []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.is_contiguous() or p.dtype != torch.float32 or grad.dtype != torch.float32:
+                    raise RuntimeError("HipAdam: parameters and gradients must be contiguous fp32")
+                st = self.state[p]
+                keep.append(grad)
+                entries.append((p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), float(g["lr"])))
+        arr = (self._T * max(len(entries), 1))()
+        for i, e in enumerate(entries):
+            arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq, arr[i].numel, arr[i].lr = e
+        self._hip.call("rn_adam_step", arr, len(entries), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                       self._hip.ptr(self._step), self._hip.ptr(self._corr), self._hip.stream())
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: state by running parameter index, one `step` per tensor."""
+        step = self._step.to(torch.float32).reshape(()).clone()
+        state, groups, at = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                state[at] = {"step": step.clone(), "exp_avg": self.state[p]["exp_avg"], "exp_avg_sq": self.state[p]["exp_avg_sq"]}
+                ids.append(at)
+                at += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        params = [p for g in self.param_groups for p in g["params"]]
+        steps = []
+        for i, p in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.state[p]["exp_avg"].copy_(st["exp_avg"])
+            self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+            steps.append(int(st["step"]))
+        if steps:
+            self._step.fill_(max(steps))
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            g["lr"] = sg.get("lr", g["lr"])
 
 
 def entropy_of(alphas):

@@ -284,3 +284,39 @@ def test_graphed_trainer_keeps_its_graph_when_the_budget_moves(hiplib):
     m.mean_count = cap + 500                    # leaves the window
     trainer.step(stream.batch())
     assert trainer.captures == 2 and trainer._capacity > cap
+
+
+def test_hip_adam_matches_torch_adam(hiplib):
+    """radnerf.train.HipAdam (rn_adam_step: one kernel for all tensors, step counter on the device) against torch.optim.Adam with
+    the reference's settings (main.py:204) over 6 steps with two learning rates: parameters and both moments within 2e-6 relative;
+    the state dict is torch.optim.Adam's (a torch optimizer loads it and continues identically)."""
+    from radnerf.train import HipAdam
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(1000003,), (64, 96), (7,), (10000, 4), (1,), (33, 3)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda", generator=gen)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:2], "lr": 5e-3}, {"params": ps[2:], "lr": 5e-4, "weight_decay": 0}]
+    oa = HipAdam(groups(pa), betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-15)
+    for step in range(6):
+        for a, b in zip(pa, pb):
+            g = torch.randn(a.shape, device="cuda", generator=gen) * (10.0 ** (step - 3))
+            if step == 2 and a.numel() > 100:
+                g[::3] = 0                                         # rows without gradient still move (dense Adam)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    def close(x, y):
+        return float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-30
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert close(a.detach(), b.detach()), i
+        assert close(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) and close(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]), i
+    assert int(oa._step.item()) == 6
+    oc = torch.optim.Adam(groups([torch.nn.Parameter(p.detach().clone()) for p in pa]), betas=(0.9, 0.99), eps=1e-15)
+    oc.load_state_dict(oa.state_dict())
+    assert all(float(s["step"]) == 6 for s in oc.state_dict()["state"].values())
+    od = HipAdam(groups(pa), betas=(0.9, 0.99), eps=1e-15)
+    od.load_state_dict(ob.state_dict())
+    assert int(od._step.item()) == 6 and close(od.state[pa[0]]["exp_avg"], ob.state[pb[0]]["exp_avg"])
+    with pytest.raises(ValueError):
+        HipAdam([{"params": pa[:1], "lr": 1e-3, "weight_decay": 0.1}])
