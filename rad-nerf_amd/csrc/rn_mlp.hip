@@ -20,6 +20,8 @@
 // inference kernel.  fp32 throughout (exact products, fp32 accumulation): results equal torch's up to summation order.
 #include "rn_common.h"
 
+#include <stdlib.h>
+
 #include "../../include/radnerf_fused.h"
 
 namespace rn {
@@ -351,8 +353,9 @@ struct Fetched {
     float v[kFetch];
 };
 
+template <bool NATIVE>
 __device__ __forceinline__ void fetch(Fetched &f, const Operand &op, uint32_t tile, uint32_t M) {
-    if (op.native) {
+    if constexpr (NATIVE) {
         const float *src = op.p + (size_t)tile * kTileFloats;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -362,13 +365,17 @@ __device__ __forceinline__ void fetch(Fetched &f, const Operand &op, uint32_t ti
 #pragma unroll
         for (int q = 0; q < kFetch; q++) {   // consecutive threads: consecutive features of one sample
             const uint32_t e = threadIdx.x + (uint32_t)q * kThreads, s = e / rows_pad, o = e - s * rows_pad, sample = tile * 32 + s;
-            f.v[q] = (e < n && sample < M && o < op.rows) ? op.p[(size_t)sample * op.ld + o] : 0.0f;
+            // unconditional load from a clamped address (a predicated load would be a branch with its own wait); what lies
+            // outside the operand is zeroed in commit(), so nothing here waits for the load
+            (void)n;
+            f.v[q] = op.p[(size_t)(sample < M ? sample : M - 1u) * op.ld + (o < op.rows ? o : 0u)];
         }
     }
 }
 
-__device__ __forceinline__ void commit(float *t, const Fetched &f, const Operand &op) {
-    if (op.native) {
+template <bool NATIVE>
+__device__ __forceinline__ void commit(float *t, const Fetched &f, const Operand &op, uint32_t tile, uint32_t M) {
+    if constexpr (NATIVE) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -380,18 +387,15 @@ __device__ __forceinline__ void commit(float *t, const Fetched &f, const Operand
 #pragma unroll
         for (int q = 0; q < kFetch; q++) {
             const uint32_t e = threadIdx.x + (uint32_t)q * kThreads, s = e / rows_pad, o = e - s * rows_pad;
-            if (e < n) t[o * kTS + (s & 1u) * 16u + (s >> 1)] = f.v[q];
+            if (e < n) t[o * kTS + (s & 1u) * 16u + (s >> 1)] = (tile * 32 + s < M && o < op.rows) ? f.v[q] : 0.0f;
         }
     }
 }
 
 // One workgroup = one job x one slice of the sample tiles.  The four waves share the staged tiles; the up to 3 x 3 output
 // blocks of 32 x 32 are dealt round-robin to the waves (<= 3 each), whose accumulators stay in registers over all tiles.
-__global__ void __launch_bounds__(kThreads, 3) k_mlp_wgrad(WArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
-    const uint32_t jb = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
-    if (jb >= p.n_jobs) return;
-    const WJob &job = p.job[jb];
+template <bool A_NATIVE, bool B_NATIVE>
+__device__ __forceinline__ void wgrad_job(const WArgs &p, const WJob &job, uint32_t part, float *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const uint32_t na = (job.a.rows + 31u) / 32u, nb = (job.b.rows + 31u) / 32u, n_blocks = na * nb;
     f32x16 acc[3];
@@ -404,20 +408,24 @@ __global__ void __launch_bounds__(kThreads, 3) k_mlp_wgrad(WArgs p) {
     for (int q = 0; q < 3; q++) { const uint32_t b = (uint32_t)wave + 4u * q; bx[q] = b / nb; by[q] = b - bx[q] * nb; }
     const uint32_t n_tiles = (p.M + 31u) >> 5;
     float *ta = lds, *tb = lds + kStageFloats;
-    Fetched fa, fb;
+    // Tiles travel global -> registers two iterations ahead of their use (two register sets, alternating): the HBM latency
+    // of a tile that is read exactly once (~3 us) is longer than the ~1 us of MFMA work per tile.
+    Fetched fa0, fb0, fa1, fb1;
+    const uint32_t stride = p.parts;
     if (part < n_tiles) {
-        fetch(fa, job.a, part, p.M);
-        fetch(fb, job.b, part, p.M);
-        commit(ta, fa, job.a);
-        commit(tb, fb, job.b);
+        fetch<A_NATIVE>(fa0, job.a, part, p.M);
+        fetch<B_NATIVE>(fb0, job.b, part, p.M);
+    }
+    if (part + stride < n_tiles) {
+        fetch<A_NATIVE>(fa1, job.a, part + stride, p.M);
+        fetch<B_NATIVE>(fb1, job.b, part + stride, p.M);
+    }
+    if (part < n_tiles) {
+        commit<A_NATIVE>(ta, fa0, job.a, part, p.M);
+        commit<B_NATIVE>(tb, fb0, job.b, part, p.M);
     }
     __syncthreads();
-    for (uint32_t tile = part; tile < n_tiles; tile += p.parts) {
-        const uint32_t next = tile + p.parts;
-        if (next < n_tiles) {
-            fetch(fa, job.a, next, p.M);
-            fetch(fb, job.b, next, p.M);
-        }
+    auto multiply = [&]() {
         // k-step t of the MFMA = samples 2 t + h of the tile: 16 consecutive floats per lane and operand
 #pragma unroll
         for (int q = 0; q < 3; q++)
@@ -435,10 +443,31 @@ __global__ void __launch_bounds__(kThreads, 3) k_mlp_wgrad(WArgs p) {
                     acc[q] = mfma32(av[u].w, bv[u].w, acc[q]);
                 }
             }
+    };
+    // iteration on tile T (in LDS): registers set `cur` is free (it was committed) -> fetch T + 2 strides into it; set
+    // `cur ^ 1` holds T + 1 stride, committed after the multiply
+    for (uint32_t tile = part; tile < n_tiles; tile += 2 * stride) {
+        if (tile + 2 * stride < n_tiles) {
+            fetch<A_NATIVE>(fa0, job.a, tile + 2 * stride, p.M);
+            fetch<B_NATIVE>(fb0, job.b, tile + 2 * stride, p.M);
+        }
+        multiply();
         __syncthreads();      // everybody has read this tile
-        if (next < n_tiles) {
-            commit(ta, fa, job.a);
-            commit(tb, fb, job.b);
+        if (tile + stride < n_tiles) {
+            commit<A_NATIVE>(ta, fa1, job.a, tile + stride, p.M);
+            commit<B_NATIVE>(tb, fb1, job.b, tile + stride, p.M);
+        }
+        __syncthreads();
+        if (tile + stride >= n_tiles) break;
+        if (tile + 3 * stride < n_tiles) {
+            fetch<A_NATIVE>(fa1, job.a, tile + 3 * stride, p.M);
+            fetch<B_NATIVE>(fb1, job.b, tile + 3 * stride, p.M);
+        }
+        multiply();
+        __syncthreads();
+        if (tile + 2 * stride < n_tiles) {
+            commit<A_NATIVE>(ta, fa0, job.a, tile + 2 * stride, p.M);
+            commit<B_NATIVE>(tb, fb0, job.b, tile + 2 * stride, p.M);
         }
         __syncthreads();
     }
@@ -450,6 +479,18 @@ __global__ void __launch_bounds__(kThreads, 3) k_mlp_wgrad(WArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) dst[(32 * bx[q] + rowmap(r, h)) * 96 + 32 * by[q] + i] = acc[q][r];
         }
+}
+
+// the operand kinds are compile-time inside a job (three combinations occur: dZ native x x row-major, native x native,
+// grad_out row-major x native): no value of the fetch pipeline crosses a data-dependent branch
+__global__ void __launch_bounds__(kThreads, 3) k_mlp_wgrad(WArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+    const uint32_t jb = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
+    if (jb >= p.n_jobs) return;
+    const WJob &job = p.job[jb];
+    if (job.a.native && job.b.native) wgrad_job<true, true>(p, job, part, lds);
+    else if (job.a.native) wgrad_job<true, false>(p, job, part, lds);
+    else wgrad_job<false, true>(p, job, part, lds);
 }
 
 __global__ void __launch_bounds__(256) k_mlp_wreduce(WArgs p) {
@@ -486,7 +527,16 @@ static void launch_with_lds(K kernel, dim3 grid, size_t shm, hipStream_t s, cons
     if (shm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(kernel, grid, dim3(kThreads), shm, s, args);
 }
-constexpr uint32_t kWParts = 256;  // workgroups (= partial sums) per weight-gradient job: 3 jobs = 3 workgroups per CU
+constexpr uint32_t kWPartsMax = 512;  // workspace is sized for this many partial sums per job
+static uint32_t wparts() {            // workgroups (= partial sums) per weight-gradient job: 3 jobs x 256 = 3 workgroups per CU
+    static uint32_t n = 0;
+    if (!n) {
+        const char *e = getenv("RN_MLP_WPARTS");
+        const long v = e ? atol(e) : 256;
+        n = (uint32_t)(v < 1 ? 1 : (v > (long)kWPartsMax ? (long)kWPartsMax : v));
+    }
+    return n;
+}
 
 }  // namespace mlp
 }  // namespace rn
@@ -504,7 +554,7 @@ size_t rn_mlp64_image_floats(uint32_t in_dim, uint32_t out_dim, uint32_t n_layer
 
 size_t rn_mlp64_tile_floats(uint32_t M) { return (size_t)((M + 31u) >> 5) * kTileFloats; }
 
-size_t rn_mlp64_wgrad_workspace(uint32_t n_layers) { return (size_t)n_layers * kWParts * 96 * 96 * sizeof(float); }
+size_t rn_mlp64_wgrad_workspace(uint32_t n_layers) { return (size_t)n_layers * kWPartsMax * 96 * 96 * sizeof(float); }
 
 int rn_mlp64_pack(const float *w0, const float *w1, const float *w_last, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                   float *image, rn_stream_t stream) {
@@ -575,9 +625,9 @@ int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uin
     RN_REQUIRE(M > 0, "mlp64_weight_grads: M must be positive");
     WArgs p{};
     p.M = M;
-    p.parts = kWParts;
+    p.parts = wparts();
     float *ws = static_cast<float *>(workspace);
-    const size_t per_job = (size_t)kWParts * 96 * 96;
+    const size_t per_job = (size_t)kWPartsMax * 96 * 96;
     uint32_t n = 0;
     // L0: dW0 = dZ0 x^T
     p.job[n] = WJob{Operand{dz0, 1u, 0u, 64u}, Operand{x, 0u, d.in_pad, d.in_pad}, ws + n * per_job, gw0, d.in_dim, d.in_dim};
@@ -589,7 +639,7 @@ int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uin
     p.job[n] = WJob{Operand{grad_out, 0u, d.out_dim, d.out_dim}, Operand{n_layers == 3 ? h1 : h0, 1u, 0u, 64u}, ws + n * per_job, gw_last, 64u, 64u};
     n++;
     p.n_jobs = n;
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(n * kWParts), dim3(kThreads), 0, as_stream(stream), p);
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(n * p.parts), dim3(kThreads), 0, as_stream(stream), p);
     hipLaunchKernelGGL(k_mlp_wreduce, dim3(div_up(96 * 96, 256), n), dim3(256), 0, as_stream(stream), p);
     return check_launch("mlp64_weight_grads");
 }
