@@ -141,7 +141,8 @@ def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1, am
     else:
         loss = loss + 1e-4 * entropy_of(out["weights_sum"]).mean()
         # ambient coordinates should stay put outside the face (nerf/utils.py:796-803), weight ramped over `iters`
-        loss_amb = (out["ambient"] * (~data["face_mask"].view(-1))).mean()
+        face = data["face_mask"].reshape(-1)
+        loss_amb = (out["ambient"] * ((~face) if face.dtype == torch.bool else (1.0 - face))).mean()   # a 0/1 float mask is the same product
         # amb_weight: the same factor as a device scalar (a captured step reads it instead of baking the Python float in)
         loss = loss + (amb_weight if amb_weight is not None else min(global_step / iters, 1.0) * lambda_amb) * loss_amb
     return pred, rgb, loss
@@ -167,13 +168,30 @@ class SyntheticTrainStream:
         # what update_extra_state samples from (main.py:183-186 hands the loader's arrays to the model)
         m.aud_features, m.poses = scene.aud_features, scene.poses
         m.eye_area = torch.full((scene.n_frames, 1), 0.25, device=scene.device)
+        self._table = None
 
     def batch(self):
+        """One gather for the whole batch: the per-pixel arrays are kept side by side in one [n_px, 15] table, the batch's
+        tensors are views of the gathered rows (key `_packed`: GraphedTrainer copies that one tensor into its static input)."""
         f, n_px = self.f, self.target.shape[1]
+        if self._table is None:
+            cols = [f["rays_o"][0], f["rays_d"][0], f["bg_coords"][0], f["bg_color"][0], self.target[0], self.face_mask[0].float().unsqueeze(-1)]
+            self._table = torch.cat([c.reshape(n_px, -1).float() for c in cols], dim=1).contiguous()
         idx = torch.randint(0, n_px, (self.n_rays,), device=self.target.device, generator=self.gen)
-        return dict(rays_o=f["rays_o"][:, idx], rays_d=f["rays_d"][:, idx], bg_coords=f["bg_coords"][:, idx], poses=f["poses"],
-                    face_mask=self.face_mask[:, idx], eye=f["eye"], auds=f["auds"], index=[self.frame],
-                    bg_color=f["bg_color"][:, idx], images=self.target[:, idx], bg_torso_color=self.target[:, idx])
+        out = self.unpack(self._table.index_select(0, idx))
+        import os
+        if os.environ.get("RN_TRAIN_PACKED", "1") == "0":       # experiment switch: separate tensors, as a generic loader would hand over
+            out = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in out.items() if not k.startswith("_")}
+        return out
+
+    def unpack(self, rows):
+        """Batch dict over the columns of `rows` [n_rays, 15]: every per-ray entry is a VIEW (face_mask stays the 0/1 float column),
+        so refreshing `rows` in place refreshes the batch."""
+        v = rows.unsqueeze(0)
+        f = self.f
+        return dict(rays_o=v[..., 0:3], rays_d=v[..., 3:6], bg_coords=v[..., 6:8], poses=f["poses"], face_mask=v[..., 14],
+                    eye=f["eye"], auds=f["auds"], index=[self.frame], bg_color=v[..., 8:11], images=v[..., 11:14],
+                    bg_torso_color=v[..., 11:14], _packed=rows, _unpack=self.unpack)
 
 
 class Trainer:
@@ -225,6 +243,7 @@ class GraphedTrainer(Trainer):
         self.capacity_step = int(capacity_step)
         self._capacity = 0
         self._graph = self._static = self._loss = self._key = None
+        self._static_index = None
         self._pool = None
         dev = next(model.parameters()).device
         self._amb_weight = torch.zeros((), dtype=torch.float32, device=dev)
@@ -237,8 +256,12 @@ class GraphedTrainer(Trainer):
         old = (self._graph, self._loss)        # stays alive until the new graph exists: a pool nobody references is dropped
         self._loss = None
         if self._static is None:
-            self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+            if "_packed" in data:        # a batch that is one table of rows: one static tensor, the step's inputs are its views
+                self._static = dict(data["_unpack"](data["_packed"].clone()))
+            else:
+                self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
             if isinstance(self._static.get("index"), (list, tuple)):     # a Python list would be uploaded inside the capture
+                self._static_index = list(self._static["index"])
                 self._static["index"] = torch.tensor(self._static["index"], dtype=torch.long, device=self._counter.device)
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
@@ -282,11 +305,19 @@ class GraphedTrainer(Trainer):
         key = (self._capacity, tuple(data["rays_o"].shape))
         if self._graph is None or key != self._key:
             self._capture(data, key)
-        for k, v in data.items():
-            if torch.is_tensor(v):
-                self._static[k].copy_(v)
-            elif k == "index" and isinstance(v, (list, tuple)) and list(v) != self._static[k].tolist():
-                self._static[k].copy_(torch.tensor(v, dtype=torch.long))
+        if "_packed" in data and "_packed" in self._static:
+            self._static["_packed"].copy_(data["_packed"])
+            for k in ("poses", "eye", "auds"):
+                if data[k] is not self._static[k]:
+                    self._static[k].copy_(data[k])
+        else:
+            for k, v in data.items():
+                if torch.is_tensor(v) and k != "_packed":
+                    self._static[k].copy_(v)
+        v = data.get("index")
+        if isinstance(v, (list, tuple)) and list(v) != self._static_index:
+            self._static["index"].copy_(torch.tensor(v, dtype=torch.long))
+            self._static_index = list(v)
         self._amb_weight.fill_(min(self.global_step / self.iters, 1.0) * self.lambda_amb)
         self._graph.replay()
         m.step_counter[m.local_step % 16].copy_(self._counter)

@@ -320,3 +320,27 @@ def test_hip_adam_matches_torch_adam(hiplib):
     assert int(od._step.item()) == 6 and close(od.state[pa[0]]["exp_avg"], ob.state[pb[0]]["exp_avg"])
     with pytest.raises(ValueError):
         HipAdam([{"params": pa[:1], "lr": 1e-3, "weight_decay": 0.1}])
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_packed_batches_train_like_separate_tensors(hiplib, monkeypatch, graphed):
+    """SyntheticTrainStream hands a batch over as views of ONE gathered table (GraphedTrainer then refreshes one static tensor per
+    step); with RN_TRAIN_PACKED=0 it hands over separate contiguous tensors as a generic loader would.  Same seeds -> same
+    samples, same noise: the loss curves agree step by step (atomics reorder sums: 2e-3 relative)."""
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream, Trainer
+    curves = {}
+    for packed in ("1", "0"):
+        monkeypatch.setenv("RN_TRAIN_PACKED", packed)
+        torch.manual_seed(11)
+        scene = _scene(64, torso=False, smooth_lips=False)
+        stream = SyntheticTrainStream(scene, n_rays=2048, seed=3)
+        m = scene.model
+        trainer = (GraphedTrainer if graphed else Trainer)(m, scene.opt, update_extra_interval=0)
+        losses = [float(trainer.step(stream.batch())) for _ in range(3)]
+        m.mean_count = 40000
+        torch.manual_seed(12)
+        losses += [float(trainer.step(stream.batch())) for _ in range(12)]
+        curves[packed] = np.array(losses)
+        if graphed:
+            assert trainer.captures == 1 and trainer.replays == 12
+    np.testing.assert_allclose(curves["1"], curves["0"], rtol=2e-3, atol=1e-7)

@@ -18,6 +18,8 @@ timeout -k 10 300 python bench.py --regime A --no-cpu-baseline > "$O/bench_hash1
 timeout -k 10 300 python bench.py --audio-batch 0 --no-cpu-baseline > "$O/bench_hash19_f32_live_audio.json" 2> "$O/bench_la.err" || { tail "$O/bench_la.err"; exit 1; }
 timeout -k 10 300 python bench.py --engine ops --steps 40 --warmup 5 --no-cpu-baseline > "$O/bench_hash19_ops_engine.json" 2> "$O/bench_ops.err" || { tail "$O/bench_ops.err"; exit 1; }
 timeout -k 10 300 python bench.py --workload train --steps 128 > "$O/bench_train.json" 2> "$O/bench_train.err" || { tail "$O/bench_train.err"; exit 1; }
+for i in 2 3 4 5; do timeout -k 10 300 python bench.py --workload train --steps 128 > "$O/bench_train_run$i.json" 2>/dev/null || exit 1; done
+timeout -k 10 300 python bench.py --loop-launch coop --no-cpu-baseline > "$O/bench_hash19_f32_loop_coop.json" 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --workload train --steps 128 --train-engine eager > "$O/bench_train_eager.json" 2> "$O/bench_train_e.err" || { tail "$O/bench_train_e.err"; exit 1; }
 timeout -k 10 300 python bench.py --workload tile --size 1024 --steps 60 --warmup 10 --no-cpu-baseline > "$O/bench_tile1024.json" 2> "$O/bench_tile.err" || { tail "$O/bench_tile.err"; exit 1; }
 # multi-rank rehearsals on this one GPU (gloo; RCCL needs a GPU per rank): 4 ranks each
@@ -35,6 +37,8 @@ for m in f32 f32x2 f16; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$m" -- python3 "$R/bench.py" --mlp $m --steps 8 --warmup 20 --no-cpu-baseline > "$O/pmc_fetch_$m/bench.json" 2> "$O/pmc_fetch_$m/err.log" || { tail "$O/pmc_fetch_$m/err.log"; exit 1; }
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$m" -- python3 "$R/bench.py" --mlp $m --steps 8 --warmup 20 --no-cpu-baseline > "$O/pmc_write_$m/bench.json" 2> "$O/pmc_write_$m/err.log" || { tail "$O/pmc_write_$m/err.log"; exit 1; }
 done
+timeout -k 10 200 python tools/bench_mlp.py > "$O/mlp_kernels.json" 2>/dev/null || exit 1
+timeout -k 10 300 python tools/train_probe.py > "$O/train_probe.json" 2>/dev/null || exit 1
 mkdir -p "$O/trace_train"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_train" -- python3 "$R/bench.py" --workload train --steps 64 --train-engine eager > "$O/trace_train/bench.json" 2> "$O/trace_train/err.log" || { tail "$O/trace_train/err.log"; exit 1; }
 cd "$R"

@@ -28,7 +28,8 @@ def main():
     for f in glob.glob(os.path.join(F, "rehearse4_*.json")):
         shutil.copy(f, os.path.join(P, f"{tag}_{os.path.basename(f)}"))
     for src, dst in (("kernels.json", "kernel_microbench.json"), ("fused_kernel.jsonl", "fused_kernel_isolated.jsonl"),
-                     ("pytest_gpu.log", "pytest_gpu.log")):
+                     ("pytest_gpu.log", "pytest_gpu.log"), ("mlp_kernels.json", "mlp_train_kernels.json"),
+                     ("train_probe.json", "train_step_probe.json")):
         if os.path.exists(os.path.join(F, src)):
             shutil.copy(os.path.join(F, src), os.path.join(P, f"{tag}_{dst}"))
     st = newest(os.path.join(F, "trace_train", "**", "*kernel_stats.csv"))
