@@ -2,7 +2,8 @@
 # One pass that produces every number DESIGN.md / profiles/ quote for round 2: full GPU test suite, smoke, bench lines (all
 # workloads and variants), rocprofv3 kernel traces, PMC traffic passes, the standalone lookup profile, training, rehearsals.
 set -o pipefail
-# PART=A: tests, smoke, bench lines, rehearsals.  PART=B: micro-benchmarks, rocprofv3 traces, counter passes, lookup profile.
+# PART=A: tests, smoke, bench lines, rehearsals.  PART=B: micro-benchmarks, rocprofv3 traces, counter passes, training profile,
+# lookup profile.  PART=C: only the tail of B (training micro-benchmarks + profile, lookup profile).
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/final2"; mkdir -p "$O"
 export TMPDIR=/tmp
 cd "$R"
@@ -37,8 +38,11 @@ for m in f32 f32x2 f16; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$m" -- python3 "$R/bench.py" --mlp $m --steps 8 --warmup 20 --no-cpu-baseline > "$O/pmc_fetch_$m/bench.json" 2> "$O/pmc_fetch_$m/err.log" || { tail "$O/pmc_fetch_$m/err.log"; exit 1; }
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$m" -- python3 "$R/bench.py" --mlp $m --steps 8 --warmup 20 --no-cpu-baseline > "$O/pmc_write_$m/bench.json" 2> "$O/pmc_write_$m/err.log" || { tail "$O/pmc_write_$m/err.log"; exit 1; }
 done
-timeout -k 10 200 python tools/bench_mlp.py > "$O/mlp_kernels.json" 2>/dev/null || exit 1
-timeout -k 10 300 python tools/train_probe.py > "$O/train_probe.json" 2>/dev/null || exit 1
+fi
+if [ "${PART:-A}" = "B" ] || [ "${PART:-A}" = "C" ]; then
+cd /tmp
+timeout -k 10 200 python "$R/tools/bench_mlp.py" > "$O/mlp_kernels.json" 2> "$O/mlp_kernels.err" || { tail "$O/mlp_kernels.err"; exit 1; }
+timeout -k 10 300 python "$R/tools/train_probe.py" > "$O/train_probe.json" 2> "$O/train_probe.err" || { tail "$O/train_probe.err"; exit 1; }
 mkdir -p "$O/trace_train"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_train" -- python3 "$R/bench.py" --workload train --steps 64 --train-engine eager > "$O/trace_train/bench.json" 2> "$O/trace_train/err.log" || { tail "$O/trace_train/err.log"; exit 1; }
 cd "$R"
