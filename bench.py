@@ -252,6 +252,7 @@ def run_train(args):
         "steps_per_s_by_segment": sps, "spread": (max(sps) - min(sps)) / (sum(sps) / len(sps)) if sps else None,
         "occupancy_refresh_ms": refresh_ms, "occupancy_refresh_share_of_step": refresh_ms / 16 / (elapsed / K * 1e3),
         "graph_captures": getattr(trainer, "captures", None), "graph_replays": getattr(trainer, "replays", None),
+        "graph_capture_log": getattr(trainer, "capture_log", None),
         "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "roofline": roof}))
 
 

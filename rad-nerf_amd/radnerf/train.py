@@ -235,25 +235,27 @@ class GraphedTrainer(Trainer):
     and therefore runs eagerly.  The refresh changes `mean_count`, the marcher's sample budget M (raymarching.py:226-229): the
     graph is captured for a row CAPACITY (the budget rounded up to a multiple of `capacity_step`, kept while the budget stays
     within it) and the budget itself is a device scalar the marcher reads (rn_march_rays_train_budget), so a refresh changes a
-    number, not the graph; rows between budget and capacity stay zero and belong to no ray.  The graph is captured again only
-    when the budget leaves the capacity window (or the batch shape changes).  Same arithmetic as Trainer.step."""
+    number, not the graph; rows between budget and capacity stay zero and belong to no ray.  A new graph is captured only
+    when the budget leaves the capacity window for a capacity not seen before (the last `max_graphs` graphs are kept: the
+    budget of a model whose density depends on the audio swings by +-20 % between refreshes).  Same arithmetic as Trainer.step."""
 
-    def __init__(self, model, opt, capacity_step=4096, **kw):
+    def __init__(self, model, opt, capacity_step=4096, max_graphs=8, **kw):
         super().__init__(model, opt, capturable=True, **kw)
         self.capacity_step = int(capacity_step)
+        self.max_graphs = int(max_graphs)
         self._capacity = 0
+        self._graphs = {}              # key -> (graph, loss): a budget that comes back to an earlier capacity replays that graph
         self._graph = self._static = self._loss = self._key = None
         self._static_index = None
-        self._pool = None
         dev = next(model.parameters()).device
         self._amb_weight = torch.zeros((), dtype=torch.float32, device=dev)
         self._counter = torch.zeros(2, dtype=torch.int32, device=dev)
         self._budget = torch.zeros(1, dtype=torch.int32, device=dev)
         self.captures = self.replays = 0
+        self.capture_log = []          # (step, budget, capacity) of every capture
 
     def _capture(self, data, key):
         m = self.model
-        old = (self._graph, self._loss)        # stays alive until the new graph exists: a pool nobody references is dropped
         self._loss = None
         if self._static is None:
             if "_packed" in data:        # a batch that is one table of rows: one static tensor, the step's inputs are its views
@@ -263,15 +265,13 @@ class GraphedTrainer(Trainer):
             if isinstance(self._static.get("index"), (list, tuple)):     # a Python list would be uploaded inside the capture
                 self._static_index = list(self._static["index"])
                 self._static["index"] = torch.tensor(self._static["index"], dtype=torch.long, device=self._counter.device)
-        if self._pool is None:
-            self._pool = torch.cuda.graph_pool_handle()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         m._static_counter = self._counter                     # renderer._head_training counts into this pair while captured
         m._sample_budget = (self._budget, self._capacity)
         try:
-            with torch.cuda.graph(g, pool=self._pool):
+            with torch.cuda.graph(g):                    # a private memory pool per graph: cached graphs never alias each other
                 _, _, loss = train_step(m, self._static, self.opt, amb_weight=self._amb_weight)
                 loss.backward()
                 self.optimizer.step()
@@ -280,8 +280,11 @@ class GraphedTrainer(Trainer):
             m._sample_budget = None
         m.local_step -= 1                                     # the capture pass went through the Python bookkeeping once
         self._graph, self._loss, self._key = g, loss, key
-        del old
+        self._graphs[key] = (g, loss)
+        while len(self._graphs) > self.max_graphs:           # drop the oldest (dicts keep insertion order); never the newest
+            del self._graphs[next(iter(self._graphs))]
         self.captures += 1
+        self.capture_log.append((self.global_step, int(self._budget.item()), self._capacity))
 
     def step(self, data):
         m = self.model
@@ -303,8 +306,13 @@ class GraphedTrainer(Trainer):
             self._capacity = -(-(budget + step // 4) // step) * step
         self._budget.fill_(budget)
         key = (self._capacity, tuple(data["rays_o"].shape))
-        if self._graph is None or key != self._key:
-            self._capture(data, key)
+        if key != self._key:
+            hit = self._graphs.pop(key, None)
+            if hit is not None:                                  # seen before: replay that graph (and mark it most recent)
+                self._graphs[key] = hit
+                self._graph, self._loss, self._key = hit[0], hit[1], key
+            else:
+                self._capture(data, key)
         if "_packed" in data and "_packed" in self._static:
             self._static["_packed"].copy_(data["_packed"])
             for k in ("poses", "eye", "auds"):
