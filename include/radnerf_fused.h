@@ -314,19 +314,24 @@ int rn_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint3
  * rn_mlp64_image_floats() floats (16-byte aligned) and is rebuilt by rn_mlp64_pack whenever a weight changes (w0 [64,in_dim],
  * w1 [64,64] (3 layers, else NULL), w_last [out_dim,64]: the nn.Linear weights).  Weight gradients are written (not
  * accumulated) in the nn.Linear layout; `workspace` needs rn_mlp64_wgrad_workspace(n_layers) bytes.  fp32 MFMA throughout:
- * equal to torch up to summation order. */
+ * equal to torch up to summation order.
+ * Constant input columns (the audio code, eye value, individual code: the same for every sample of a call) need not be
+ * materialised: the MLP then reads only the first in_dim columns of a wider w0 (`ld0` = its row stride; gw0 is written with
+ * the same stride, columns in_dim .. ld0-1 untouched) and the constants enter as bias0 [64] = w0[:, in_dim:] . constants, added
+ * to the first layer's pre-activation; grad_bias0 [64] (nullable; needs in_dim <= 92) receives its gradient, from which the
+ * caller derives the gradients of w0[:, in_dim:] (outer product with the constants) and of the constants. */
 size_t rn_mlp64_image_floats(uint32_t in_dim, uint32_t out_dim, uint32_t n_layers);
 size_t rn_mlp64_tile_floats(uint32_t M);
 size_t rn_mlp64_wgrad_workspace(uint32_t n_layers);
-int rn_mlp64_pack(const float *w0, const float *w1, const float *w_last, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
-                  float *image, rn_stream_t stream);
-int rn_mlp64_forward(const float *x, uint32_t M, const float *image, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers, float *out,
-                     float *h0, float *h1, rn_stream_t stream);
+int rn_mlp64_pack(const float *w0, uint32_t ld0, const float *w1, const float *w_last, uint32_t in_dim, uint32_t out_dim,
+                  uint32_t n_layers, float *image, rn_stream_t stream);
+int rn_mlp64_forward(const float *x, uint32_t M, const float *image, const float *bias0, uint32_t in_dim, uint32_t out_dim,
+                     uint32_t n_layers, float *out, float *h0, float *h1, rn_stream_t stream);
 int rn_mlp64_backward(const float *grad_out, uint32_t M, const float *image, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                       const float *h0, const float *h1, float *grad_x, float *dz0, float *dz1, rn_stream_t stream);
 int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
-                          const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, float *gw1,
-                          float *gw_last, void *workspace, rn_stream_t stream);
+                          const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, uint32_t ld0,
+                          float *gw1, float *gw_last, float *grad_bias0, void *workspace, rn_stream_t stream);
 
 /* ---- optimizer update of the training step ------------------------------------------------------------------------
  * torch.optim.Adam as main.py:204 configures it (betas, eps; no weight decay, no amsgrad) for `count` tensors in ONE

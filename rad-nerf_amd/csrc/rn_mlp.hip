@@ -81,6 +81,7 @@ __device__ __forceinline__ void tile_load(const float *__restrict__ src, Acc32 &
 // transposed: last wide^T [32 steps] | L1^T [32 steps] | L0^T [32 steps][2 h][32 j][4 rt] (rows = input features)
 struct Dims {
     uint32_t in_dim, in_pad, out_dim, n_layers, nn, wide;   // nn = narrow rows (out_dim % 64 or out_dim), wide = out_dim >= 64
+    uint32_t ld0;                                           // row stride of w0 (>= in_dim: the MLP may read a column block of a wider nn.Linear)
     __host__ __device__ uint32_t s0() const { return in_pad / 2; }
     __host__ __device__ uint32_t off_l1() const { return s0() * kStepF; }
     __host__ __device__ uint32_t off_lw() const { return off_l1() + (n_layers == 3 ? 32u * kStepF : 0u); }
@@ -94,8 +95,9 @@ struct Dims {
     __host__ __device__ uint32_t rt_in() const { return (in_pad + 31u) / 32u; }
 };
 
-static bool make_dims(uint32_t in_dim, uint32_t out_dim, uint32_t n_layers, Dims &d) {
+static bool make_dims(uint32_t in_dim, uint32_t out_dim, uint32_t n_layers, Dims &d, uint32_t ld0 = 0) {
     d.in_dim = in_dim;
+    d.ld0 = ld0 ? ld0 : in_dim;
     d.in_pad = (in_dim + 3u) & ~3u;
     d.out_dim = out_dim;
     d.n_layers = n_layers;
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(256) k_mlp_pack(const float *__restrict__ w0, 
             const uint32_t row = 32 * rt + j;
             if (e < d.off_l1()) {                                  // L0: k = 4 (s / 2) + 2 h + (s & 1)
                 const uint32_t k = 4 * (s >> 1) + 2 * h + (s & 1);
-                v = k < d.in_dim ? w0[row * d.in_dim + k] : 0.0f;
+                v = k < d.in_dim ? w0[row * d.ld0 + k] : 0.0f;
             } else if (e < d.off_lw()) {                           // L1: k = kmap
                 v = w1[row * 64 + kmap((int)s, (int)h)];
             } else {                                               // last layer, wide rows nn .. nn + 63
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256) k_mlp_pack(const float *__restrict__ w0, 
         } else if (t < d.off_tn()) {                               // L0^T: rows = input features (in_pad <= 96 -> 3 row tiles of 4)
             const uint32_t q = t - d.off_t0(), s = q / kStepT, rem = q % kStepT, h = rem / 128, j = (rem % 128) / 4, rt = rem % 4;
             const uint32_t row = 32 * rt + j, k = (uint32_t)kmap((int)s, (int)h);
-            v = row < d.in_dim ? w0[k * d.in_dim + row] : 0.0f;
+            v = row < d.in_dim ? w0[k * d.ld0 + row] : 0.0f;
         } else {                                                   // narrow rows again (the backward kernel stages only this image)
             const uint32_t q0 = t - d.off_tn(), o = q0 / 64, h = (q0 % 64) / 32, q = q0 % 32;
             v = wl[o * 64 + 32 * (q >> 4) + rowmap((int)(q & 15), (int)h)];
@@ -153,6 +155,7 @@ struct FwdArgs {
     Dims d;
     float *out;            // [M, out_dim]
     float *h0, *h1;        // native tiles [n_tiles][2048]; h1 only with 3 layers
+    const float *bias0;    // [64] added to the first layer's pre-activation (nullable): the per-call constant input columns
 };
 
 template <int NN, bool WIDE, bool HID2>
@@ -169,7 +172,14 @@ __global__ void __launch_bounds__(kThreads) k_mlp_fwd(FwdArgs p) {
         const uint32_t sample = tile * 32 + j;
         const bool live = sample < p.M;
         Acc32 a, b;
-        acc_zero(a);
+        if (p.bias0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) a.v[rt][r] = p.bias0[32 * rt + rowmap(r, h)];
+        } else {
+            acc_zero(a);
+        }
         {
             const float *row = p.x + (size_t)sample * d.in_pad + 2 * h;
             const uint32_t nq = d.in_pad / 4;
@@ -331,12 +341,14 @@ __global__ void __launch_bounds__(kThreads) k_mlp_bwd(BwdArgs p) {
 struct Operand {
     const float *p;
     uint32_t native, ld, rows;  // rows: real feature count (<= 96)
+    uint32_t ones;              // row-major only: one more feature that is 1 for every sample (its gradient column is the bias gradient)
 };
 struct WJob {
     Operand a, b;
     float *partial;             // [parts][96 * 96], this job's slice of the workspace
     float *out;                 // [a.rows, out_ld] nn.Linear layout
     uint32_t out_ld, out_cols;  // columns written (= b real features)
+    float *out_bias;            // [a.rows]: the column of b's `ones` feature (nullable)
 };
 constexpr int kMaxJobs = 3;
 struct WArgs {
@@ -361,7 +373,7 @@ __device__ __forceinline__ void fetch(Fetched &f, const Operand &op, uint32_t ti
 #pragma unroll
         for (int q = 0; q < 8; q++) f.v[q] = src[(wave * 8 + q) * 64 + lane];
     } else {
-        const uint32_t rows_pad = (op.rows + 31u) & ~31u, n = rows_pad * 32u;
+        const uint32_t rows_pad = (op.rows + op.ones + 31u) & ~31u, n = rows_pad * 32u;
 #pragma unroll
         for (int q = 0; q < kFetch; q++) {   // consecutive threads: consecutive features of one sample
             const uint32_t e = threadIdx.x + (uint32_t)q * kThreads, s = e / rows_pad, o = e - s * rows_pad, sample = tile * 32 + s;
@@ -383,11 +395,12 @@ __device__ __forceinline__ void commit(float *t, const Fetched &f, const Operand
             t[(32 * rt + rowmap(r, h)) * kTS + (j & 1) * 16 + (j >> 1)] = f.v[q];
         }
     } else {
-        const uint32_t rows_pad = (op.rows + 31u) & ~31u, n = rows_pad * 32u;
+        const uint32_t rows_pad = (op.rows + op.ones + 31u) & ~31u, n = rows_pad * 32u;
 #pragma unroll
         for (int q = 0; q < kFetch; q++) {
             const uint32_t e = threadIdx.x + (uint32_t)q * kThreads, s = e / rows_pad, o = e - s * rows_pad;
-            if (e < n) t[o * kTS + (s & 1u) * 16u + (s >> 1)] = (tile * 32 + s < M && o < op.rows) ? f.v[q] : 0.0f;
+            const bool in_tile = tile * 32 + s < M;
+            if (e < n) t[o * kTS + (s & 1u) * 16u + (s >> 1)] = (in_tile && o < op.rows) ? f.v[q] : ((in_tile && op.ones && o == op.rows) ? 1.0f : 0.0f);
         }
     }
 }
@@ -397,7 +410,7 @@ __device__ __forceinline__ void commit(float *t, const Fetched &f, const Operand
 template <bool A_NATIVE, bool B_NATIVE>
 __device__ __forceinline__ void wgrad_job(const WArgs &p, const WJob &job, uint32_t part, float *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-    const uint32_t na = (job.a.rows + 31u) / 32u, nb = (job.b.rows + 31u) / 32u, n_blocks = na * nb;
+    const uint32_t na = (job.a.rows + job.a.ones + 31u) / 32u, nb = (job.b.rows + job.b.ones + 31u) / 32u, n_blocks = na * nb;
     f32x16 acc[3];
 #pragma unroll
     for (int q = 0; q < 3; q++)
@@ -499,7 +512,8 @@ __global__ void __launch_bounds__(256) k_mlp_wreduce(WArgs p) {
     const WJob &job = p.job[jb];
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     const uint32_t row = e / 96, col = e % 96;
-    if (row >= job.a.rows || col >= job.out_cols) return;
+    const bool bias_col = job.out_bias && job.b.ones && col == job.b.rows;
+    if (row >= job.a.rows || (col >= job.out_cols && !bias_col)) return;
     const float *src = job.partial + row * 96 + col;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t q = 0;
@@ -508,7 +522,9 @@ __global__ void __launch_bounds__(256) k_mlp_wreduce(WArgs p) {
         for (int u = 0; u < 8; u++) s[u] += src[(size_t)(q + u) * (96 * 96)];
     }
     for (; q < p.parts; q++) s[0] += src[(size_t)q * (96 * 96)];
-    job.out[row * job.out_ld + col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    const float total = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (bias_col) job.out_bias[row] = total;
+    else job.out[row * job.out_ld + col] = total;
 }
 
 static int num_cus() {
@@ -556,10 +572,11 @@ size_t rn_mlp64_tile_floats(uint32_t M) { return (size_t)((M + 31u) >> 5) * kTil
 
 size_t rn_mlp64_wgrad_workspace(uint32_t n_layers) { return (size_t)n_layers * kWPartsMax * 96 * 96 * sizeof(float); }
 
-int rn_mlp64_pack(const float *w0, const float *w1, const float *w_last, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
+int rn_mlp64_pack(const float *w0, uint32_t ld0, const float *w1, const float *w_last, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                   float *image, rn_stream_t stream) {
     Dims d;
-    RN_REQUIRE(make_dims(in_dim, out_dim, n_layers, d), "mlp64: unsupported shape (hidden 64, 2 or 3 layers, in <= 96, out <= 4 or 64 .. 68)");
+    RN_REQUIRE(ld0 >= in_dim, "mlp64_pack: ld0 (row stride of w0) must be >= in_dim");
+    RN_REQUIRE(make_dims(in_dim, out_dim, n_layers, d, ld0), "mlp64: unsupported shape (hidden 64, 2 or 3 layers, in <= 96, out <= 4 or 64 .. 68)");
     RN_REQUIRE(w0 && w_last && image && (n_layers == 2 || w1) && ((uintptr_t)image & 15u) == 0, "mlp64_pack: null / unaligned pointer");
     const uint32_t n = d.fwd_floats() + d.bwd_floats();
     hipLaunchKernelGGL(k_mlp_pack, dim3(div_up(n, 256)), dim3(256), 0, as_stream(stream), w0, w1, w_last, d, image);
@@ -581,14 +598,14 @@ int rn_mlp64_pack(const float *w0, const float *w1, const float *w_last, uint32_
         }                                                                                                                         \
     } while (0)
 
-int rn_mlp64_forward(const float *x, uint32_t M, const float *image, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers, float *out,
-                     float *h0, float *h1, rn_stream_t stream) {
+int rn_mlp64_forward(const float *x, uint32_t M, const float *image, const float *bias0, uint32_t in_dim, uint32_t out_dim,
+                     uint32_t n_layers, float *out, float *h0, float *h1, rn_stream_t stream) {
     if (M == 0) return RN_OK;
     Dims d;
     RN_REQUIRE(make_dims(in_dim, out_dim, n_layers, d), "mlp64: unsupported shape (hidden 64, 2 or 3 layers, in <= 96, out <= 4 or 64 .. 68)");
     RN_REQUIRE(x && image && out && h0 && (n_layers == 2 || h1), "mlp64_forward: null pointer");
     RN_REQUIRE(((uintptr_t)x & 7u) == 0 && ((uintptr_t)image & 15u) == 0, "mlp64_forward: x must be 8-byte, image 16-byte aligned");
-    FwdArgs p{x, M, image, d, out, h0, h1};
+    FwdArgs p{x, M, image, d, out, h0, h1, bias0};
     const uint32_t n_tiles = (M + 31u) >> 5;
     uint32_t blocks = div_up(n_tiles, kWaves);
     const uint32_t cap = (uint32_t)num_cus() * 2u;
@@ -617,12 +634,14 @@ int rn_mlp64_backward(const float *grad_out, uint32_t M, const float *image, uin
 }
 
 int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
-                          const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, float *gw1, float *gw_last,
-                          void *workspace, rn_stream_t stream) {
+                          const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, uint32_t ld0, float *gw1,
+                          float *gw_last, float *grad_bias0, void *workspace, rn_stream_t stream) {
     Dims d;
     RN_REQUIRE(make_dims(in_dim, out_dim, n_layers, d), "mlp64: unsupported shape (hidden 64, 2 or 3 layers, in <= 96, out <= 4 or 64 .. 68)");
     RN_REQUIRE(x && grad_out && h0 && dz0 && gw0 && gw_last && workspace && (n_layers == 2 || (h1 && dz1 && gw1)), "mlp64_weight_grads: null pointer");
     RN_REQUIRE(M > 0, "mlp64_weight_grads: M must be positive");
+    RN_REQUIRE(ld0 >= in_dim, "mlp64_weight_grads: ld0 (row stride of gw0) must be >= in_dim");
+    RN_REQUIRE(!grad_bias0 || d.in_pad + 1u <= 96u, "mlp64_weight_grads: a bias gradient needs in_dim <= 92");
     WArgs p{};
     p.M = M;
     p.parts = wparts();
@@ -630,13 +649,13 @@ int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uin
     const size_t per_job = (size_t)kWPartsMax * 96 * 96;
     uint32_t n = 0;
     // L0: dW0 = dZ0 x^T
-    p.job[n] = WJob{Operand{dz0, 1u, 0u, 64u}, Operand{x, 0u, d.in_pad, d.in_pad}, ws + n * per_job, gw0, d.in_dim, d.in_dim};
+    p.job[n] = WJob{Operand{dz0, 1u, 0u, 64u, 0u}, Operand{x, 0u, d.in_pad, d.in_pad, grad_bias0 ? 1u : 0u}, ws + n * per_job, gw0, ld0, d.in_dim, grad_bias0};
     n++;
     if (n_layers == 3) {
-        p.job[n] = WJob{Operand{dz1, 1u, 0u, 64u}, Operand{h0, 1u, 0u, 64u}, ws + n * per_job, gw1, 64u, 64u};
+        p.job[n] = WJob{Operand{dz1, 1u, 0u, 64u, 0u}, Operand{h0, 1u, 0u, 64u, 0u}, ws + n * per_job, gw1, 64u, 64u, nullptr};
         n++;
     }
-    p.job[n] = WJob{Operand{grad_out, 0u, d.out_dim, d.out_dim}, Operand{n_layers == 3 ? h1 : h0, 1u, 0u, 64u}, ws + n * per_job, gw_last, 64u, 64u};
+    p.job[n] = WJob{Operand{grad_out, 0u, d.out_dim, d.out_dim, 0u}, Operand{n_layers == 3 ? h1 : h0, 1u, 0u, 64u, 0u}, ws + n * per_job, gw_last, 64u, 64u, nullptr};
     n++;
     p.n_jobs = n;
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(n * p.parts), dim3(kThreads), 0, as_stream(stream), p);

@@ -125,6 +125,20 @@ class MLP(nn.Module):
             nn.Linear(dim_in if l == 0 else dim_hidden, dim_out if l == num_layers - 1 else dim_hidden, bias=False)
             for l in range(num_layers)])
 
+    def forward_split(self, x, constants):
+        """forward(cat[x, constant.repeat(rows) for constant in constants]) -- the form every call of the path has
+        (nerf/network.py:236, 262, 274: the audio code / eye value / individual code repeated for every sample).  The training
+        kernels never materialise the repeats: the constants enter the first layer as a bias."""
+        consts = [c.reshape(1, -1) for c in constants if c is not None]
+        if not consts:
+            return self.forward(x)
+        training_shape = x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.dtype == torch.float32 and \
+            not torch.is_autocast_enabled()
+        if training_shape and x.shape[0] >= 1024 and _mlp_kernels() is not None and x.shape[1] <= 92 and \
+                _mlp_kernels().supported(x.shape[1], self.dim_out, self.dim_hidden, self.num_layers):
+            return _mlp_kernels().fused_mlp(x, [layer.weight for layer in self.net], torch.cat(consts, dim=1))
+        return self.forward(torch.cat([x] + [c.to(x.dtype).repeat(x.shape[0], 1) for c in consts], dim=-1))
+
     def forward(self, x):
         training_shape = x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.dtype == torch.float32 and \
             not torch.is_autocast_enabled()
@@ -228,13 +242,10 @@ class NeRFNetwork(NeRFRenderer):
             enc_w = self.encoder_ambient(ambient, bound=1)
         else:
             enc_x = self.encoder(x, bound=self.bound)
-            ambient = self.ambient_net(torch.cat([enc_x, enc_a.repeat(x.shape[0], 1)], dim=1)).float()
+            ambient = self.ambient_net.forward_split(enc_x, [enc_a]).float()
             ambient = torch.tanh(ambient)
             enc_w = self.encoder_ambient(ambient, bound=1)
-        parts = [enc_x, enc_w]
-        if e is not None:
-            parts.append(e.repeat(x.shape[0], 1))
-        return self.sigma_net(torch.cat(parts, dim=-1)), ambient
+        return self.sigma_net.forward_split(torch.cat([enc_x, enc_w], dim=-1), [e]), ambient
 
     def forward(self, x, d, enc_a, c, e=None):
         # nerf/network.py:222-283; x: [N,3] in [-bound,bound], d: [N,3], enc_a: [1,64], c: [ind_dim], e: [1,1]
@@ -242,10 +253,7 @@ class NeRFNetwork(NeRFRenderer):
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
         enc_d = self.encoder_dir(d)
-        parts = [enc_d, geo_feat]
-        if c is not None:
-            parts.append(c.repeat(x.shape[0], 1))
-        color = torch.sigmoid(self.color_net(torch.cat(parts, dim=-1)))
+        color = torch.sigmoid(self.color_net.forward_split(torch.cat([enc_d, geo_feat], dim=-1), [c]))
         return sigma, color, ambient
 
     def density(self, x, enc_a, e=None):

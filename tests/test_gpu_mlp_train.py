@@ -68,6 +68,39 @@ def test_fused_mlp_matches_torch_autograd(hiplib, shape, M):
         _close(g, r, 1e-4)
 
 
+@pytest.mark.parametrize("in_x,in_c,dim_out,n_layers", [(32, 64, 2, 3), (64, 1, 65, 3), (80, 4, 3, 2), (30, 7, 65, 3)])
+@pytest.mark.parametrize("M", [33, 20011])
+def test_constant_inputs_enter_as_a_bias(hiplib, in_x, in_c, dim_out, n_layers, M):
+    """fused_mlp(x, weights, constants): the columns that are the same for every sample (audio code, eye, individual code --
+    nerf/network.py:236, 262, 274 repeat them N times and concatenate) are folded into a first-layer bias; outputs and ALL
+    gradients (x, the constants, every weight incl. the constant columns of the first layer) equal the concatenated formulation."""
+    from radnerf import mlp_train
+    gen = torch.Generator(device="cuda").manual_seed(M + in_x)
+    ws = _weights(in_x + in_c, dim_out, n_layers, gen)
+    x = (torch.rand(M, in_x, device="cuda", generator=gen) * 2 - 1).requires_grad_(True)
+    c = (torch.rand(1, in_c, device="cuda", generator=gen) * 2 - 1).requires_grad_(True)
+    gy = torch.rand(M, dim_out, device="cuda", generator=gen) * 2 - 1
+    with torch.no_grad():
+        z = torch.cat([x, c.repeat(M, 1)], 1).double()
+        ambiguous = torch.zeros(M, dtype=torch.bool, device="cuda")
+        for w in ws[:-1]:
+            z = z @ w.double().t()
+            ambiguous |= (z.abs() < 1e-5).any(1)
+            z = z.clamp_min(0)
+        gy[ambiguous] = 0
+    y = mlp_train.fused_mlp(x, ws, c)
+    grads = torch.autograd.grad(y, [x, c] + ws, gy)
+    xr, cr = x.detach().clone().requires_grad_(True), c.detach().clone().requires_grad_(True)
+    wr = [w.detach().clone().requires_grad_(True) for w in ws]
+    yr = _reference(torch.cat([xr, cr.repeat(M, 1)], 1), wr)
+    ref = torch.autograd.grad(yr, [xr, cr] + wr, gy)
+    _close(y, yr, 2e-5)
+    _close(grads[0], ref[0], 2e-5)
+    for g, r in zip(grads[1:], ref[1:]):
+        assert g.shape == r.shape
+        _close(g, r, 1e-4)
+
+
 def test_mlp_module_uses_the_kernels_and_trains_like_the_linear_stack(hiplib, monkeypatch):
     """radnerf.network.MLP routes CUDA fp32 training batches through the kernels; RN_MLP_TRAIN=torch keeps nn.Linear.  A few SGD
     steps on a regression target end at the same weights (1e-4)."""

@@ -41,12 +41,12 @@ def main():
         P = hip.ptr
         w1 = P(ws[1]) if nl == 3 else None
         calls = {
-            "pack": lambda: hip.call("rn_mlp64_pack", P(ws[0]), w1, P(ws[-1]), din, dout, nl, P(image), s),
-            "forward": lambda: hip.call("rn_mlp64_forward", P(x), M, P(image), din, dout, nl, P(y), P(h0), P(h1) if nl == 3 else None, s),
+            "pack": lambda: hip.call("rn_mlp64_pack", P(ws[0]), din, w1, P(ws[-1]), din, dout, nl, P(image), s),
+            "forward": lambda: hip.call("rn_mlp64_forward", P(x), M, P(image), None, din, dout, nl, P(y), P(h0), P(h1) if nl == 3 else None, s),
             "backward": lambda: hip.call("rn_mlp64_backward", P(gy), M, P(image), din, dout, nl, P(h0), P(h1) if nl == 3 else None, P(gx), P(dz0),
                                          P(dz1) if nl == 3 else None, s),
             "weight_grads": lambda: hip.call("rn_mlp64_weight_grads", P(x), P(gy), M, din, dout, nl, P(h0), P(h1) if nl == 3 else None, P(dz0),
-                                             P(dz1) if nl == 3 else None, P(gws[0]), P(gws[1]) if nl == 3 else None, P(gws[-1]), P(wsp), s),
+                                             P(dz1) if nl == 3 else None, P(gws[0]), din, P(gws[1]) if nl == 3 else None, P(gws[-1]), None, P(wsp), s),
         }
         res = {}
         for k, fn in calls.items():
