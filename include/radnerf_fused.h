@@ -333,6 +333,22 @@ int rn_mlp64_weight_grads(const float *x, const float *grad_out, uint32_t M, uin
                           const float *h0, const float *h1, const float *dz0, const float *dz1, float *gw0, uint32_t ld0,
                           float *gw1, float *gw_last, float *grad_bias0, void *workspace, rn_stream_t stream);
 
+/* ---- elementwise glue of the training step (one kernel per direction where PyTorch takes 3 - 15) -------------------------
+ * rn_head_mid_*: between sigma_net and color_net (nerf/network.py:266-276): sigma = trunc_exp(h[:, 0]) (activation.py:5-17),
+ * x_color [M, n_sh + 64] = cat[enc_d [M, n_sh], h[:, 1:65]]; backward assembles grad_h [M, 65] from grad_sigma and the geo_feat
+ * columns of grad_x_color.  rn_abs_sum2_*: ambient.abs().sum(-1) for [M, 2] (nerf/renderer.py:216).
+ * rn_train_loss: the head's training loss (nerf/utils.py:772-803: mean squared error + 1e-4 mean binary entropy of
+ * clamp(weights_sum, 1e-5, 1 - 1e-5) + *w_amb * mean(ambient * (1 - face))) over N rays and its gradients with respect to
+ * pred [N, 3], weights_sum [N], ambient [N] in one launch; face [N] is the 0 / 1 face mask as floats, w_amb a device scalar. */
+int rn_head_mid_forward(const float *h, const float *enc_d, uint32_t M, uint32_t n_sh, float *sigma, float *x_color, rn_stream_t stream);
+int rn_head_mid_backward(const float *h, const float *grad_sigma, const float *grad_x_color, uint32_t M, uint32_t n_sh, float *grad_h,
+                         rn_stream_t stream);
+int rn_abs_sum2_forward(const float *a, uint32_t M, float *out, rn_stream_t stream);
+int rn_abs_sum2_backward(const float *a, const float *grad_out, uint32_t M, float *grad_a, rn_stream_t stream);
+int rn_train_loss(const float *pred, const float *target, const float *weights_sum, const float *ambient, const float *face,
+                  const float *w_amb, uint32_t N, float *loss, float *grad_pred, float *grad_weights_sum, float *grad_ambient,
+                  rn_stream_t stream);
+
 /* ---- optimizer update of the training step ------------------------------------------------------------------------
  * torch.optim.Adam as main.py:204 configures it (betas, eps; no weight decay, no amsgrad) for `count` tensors in ONE
  * launch (+ a one-thread launch that advances *step and computes the bias corrections in double, as Python does):

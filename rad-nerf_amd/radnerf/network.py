@@ -90,6 +90,17 @@ class _SkinnyLinear(torch.autograd.Function):
 
 _MLP_KERNELS = []
 _AUDIO_KERNELS = []
+_TRAIN_GLUE = []
+
+
+def _train_glue():
+    """radnerf.train_glue (needs the HIP library and a GPU), or None on the CPU."""
+    if not torch.cuda.is_available():
+        return None
+    if not _TRAIN_GLUE:
+        from . import train_glue
+        _TRAIN_GLUE.append(train_glue)
+    return _TRAIN_GLUE[0]
 
 
 def _audio_kernels(model):
@@ -250,10 +261,14 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d, enc_a, c, e=None):
         # nerf/network.py:222-283; x: [N,3] in [-bound,bound], d: [N,3], enc_a: [1,64], c: [ind_dim], e: [1,1]
         h, ambient = self._geometry(x, enc_a, e)
-        sigma = trunc_exp(h[..., 0])
-        geo_feat = h[..., 1:]
         enc_d = self.encoder_dir(d)
-        color = torch.sigmoid(self.color_net.forward_split(torch.cat([enc_d, geo_feat], dim=-1), [c]))
+        glue = _train_glue()
+        if glue is not None and h.dim() == 2 and h.shape[1] == 65 and glue.enabled(h, enc_d) and not enc_d.requires_grad:
+            sigma, color_in = glue.head_mid(h, enc_d)           # one kernel: trunc_exp(h[:, 0]) and cat[enc_d, h[:, 1:]]
+        else:
+            sigma = trunc_exp(h[..., 0])
+            color_in = torch.cat([enc_d, h[..., 1:]], dim=-1)
+        color = torch.sigmoid(self.color_net.forward_split(color_in, [c]))
         return sigma, color, ambient
 
     def density(self, x, enc_a, e=None):

@@ -191,8 +191,15 @@ class NeRFRenderer(nn.Module):
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
         sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
-        weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(self.density_scale * sigmas, rgbs,
-                                                                                   ambient.abs().sum(-1), deltas, rays)
+        from .network import _train_glue
+        glue = _train_glue()
+        if glue is not None and ambient.dim() == 2 and ambient.shape[1] == 2 and glue.enabled(ambient):
+            ambient_abs = glue.abs_sum2(ambient)
+        else:
+            ambient_abs = ambient.abs().sum(-1)
+        if self.density_scale != 1:
+            sigmas = self.density_scale * sigmas
+        weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient_abs, deltas, rays)
         return dict(weights_sum=weights_sum, ambient=ambient_sum, depth=depth, image=image)
 
     # ---------------------------------------------------------------------------------------------- torso layer

@@ -135,6 +135,13 @@ def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1, am
                        index=data["index"], staged=False, bg_color=data["bg_color"], perturb=True, force_all_rays=False,
                        dt_gamma=opt.dt_gamma, max_steps=opt.max_steps)
     pred = out["torso_color"] if torso else out["image"]
+    if not torso and pred.is_cuda:
+        from . import train_glue
+        face = data["face_mask"].reshape(-1)
+        if train_glue.enabled(pred, rgb, out["weights_sum"], out["ambient"]):
+            w = amb_weight if amb_weight is not None else torch.full((1,), min(global_step / iters, 1.0) * lambda_amb, device=pred.device)
+            loss = train_glue.train_loss(pred, rgb, out["weights_sum"], out["ambient"], face if face.dtype == torch.float32 else face.float(), w)
+            return pred, rgb, loss
     loss = torch.nn.functional.mse_loss(pred, rgb, reduction="none").mean(-1).mean()
     if torso:
         loss = loss + 1e-4 * entropy_of(out["torso_alpha"]).mean()

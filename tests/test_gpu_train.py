@@ -344,3 +344,69 @@ def test_packed_batches_train_like_separate_tensors(hiplib, monkeypatch, graphed
         if graphed:
             assert trainer.captures == 1 and trainer.replays == 12
     np.testing.assert_allclose(curves["1"], curves["0"], rtol=2e-3, atol=1e-7)
+
+
+def test_glue_kernels_match_the_torch_expressions(hiplib, monkeypatch):
+    """radnerf.train_glue (rn_head_mid_*, rn_abs_sum2_*, rn_train_loss) against the PyTorch expressions they replace
+    (nerf/network.py:266-276, nerf/renderer.py:216, nerf/utils.py:772-803): values and gradients, element by element."""
+    from activation import trunc_exp
+    from radnerf import train_glue as tg
+    from radnerf.train import entropy_of
+    g = torch.Generator(device="cuda").manual_seed(2)
+    M, N = 5003, 4096
+    h = (torch.randn(M, 65, device="cuda", generator=g) * 3).requires_grad_(True)
+    h.data[::17, 0] = 20.0                                     # beyond the clamp of trunc_exp's backward
+    enc_d = torch.randn(M, 16, device="cuda", generator=g)
+    sig, xc = tg.head_mid(h, enc_d)
+    hr = h.detach().clone().requires_grad_(True)
+    sig_r, xc_r = trunc_exp(hr[:, 0]), torch.cat([enc_d, hr[:, 1:]], -1)
+    gs, gx = torch.randn(M, device="cuda", generator=g), torch.randn(M, 80, device="cuda", generator=g)
+    (ga,), (gb,) = torch.autograd.grad([sig, xc], [h], [gs, gx]), torch.autograd.grad([sig_r, xc_r], [hr], [gs, gx])
+    assert torch.allclose(sig, sig_r, rtol=2e-6, atol=0) and torch.equal(xc, xc_r) and torch.allclose(ga, gb, rtol=2e-6, atol=0)
+    a = torch.randn(M, 2, device="cuda", generator=g).requires_grad_(True)
+    a.data[3] = 0.0
+    ar = a.detach().clone().requires_grad_(True)
+    go = torch.randn(M, device="cuda", generator=g)
+    assert torch.equal(tg.abs_sum2(a), ar.abs().sum(-1))
+    assert torch.equal(torch.autograd.grad(tg.abs_sum2(a), a, go)[0], torch.autograd.grad(ar.abs().sum(-1), ar, go)[0])
+    # the loss: weights_sum incl. values outside the entropy clamp
+    pred = torch.rand(1, N, 3, device="cuda", generator=g).requires_grad_(True)
+    tgt = torch.rand(1, N, 3, device="cuda", generator=g)
+    ws = torch.rand(N, device="cuda", generator=g)
+    ws[:64] = 0.0; ws[64:128] = 1.0; ws[128] = 1e-5
+    ws.requires_grad_(True)
+    amb = torch.rand(N, device="cuda", generator=g).requires_grad_(True)
+    face = (torch.rand(1, N, device="cuda", generator=g) > 0.5)
+    w_amb = torch.tensor([0.037], device="cuda")
+    loss = tg.train_loss(pred, tgt, ws, amb, face.float(), w_amb)
+    ref = torch.nn.functional.mse_loss(pred, tgt, reduction="none").mean(-1).mean() + 1e-4 * entropy_of(ws).mean() + \
+        w_amb[0] * (amb * (~face.view(-1))).mean()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    ga = torch.autograd.grad(loss, [pred, ws, amb])
+    gb = torch.autograd.grad(ref, [pred, ws, amb])
+    for x, y in zip(ga, gb):
+        assert torch.allclose(x, y, rtol=2e-5, atol=1e-12), float((x - y).abs().max())
+
+
+def test_train_step_with_glue_kernels_equals_the_torch_step(hiplib, monkeypatch):
+    """One training step with RN_TRAIN_GLUE=hip against RN_TRAIN_GLUE=torch on identical models and batch: same loss and
+    parameter gradients (summation order of the scatter-adds aside)."""
+    from radnerf.train import SyntheticTrainStream, train_step
+    res = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("RN_TRAIN_GLUE", mode)
+        torch.manual_seed(4)
+        scene = _scene(64, torso=False, smooth_lips=False)
+        stream = SyntheticTrainStream(scene, n_rays=2048, seed=1)
+        m = scene.model
+        m.train()
+        torch.manual_seed(9)
+        _, _, loss = train_step(m, stream.batch(), scene.opt, global_step=1000)
+        params = [p for n, p in m.named_parameters() if not n.startswith("torso") and "individual_codes_torso" not in n and p.requires_grad]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        res[mode] = (float(loss), [None if gr is None else gr.clone() for gr in grads])
+    assert abs(res["hip"][0] - res["torch"][0]) <= 1e-5 * abs(res["torch"][0])
+    for a, b in zip(res["hip"][1], res["torch"][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12
