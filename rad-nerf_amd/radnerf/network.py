@@ -103,7 +103,7 @@ def _train_glue():
     return _TRAIN_GLUE[0]
 
 
-def _audio_kernels(model):
+def _audio_kernels(model, need_grad=True):
     """radnerf.audio when its kernels cover the model's audio nets, or None (RN_AUDIO_TRAIN=torch: the nn.Module path)."""
     import os
     if os.environ.get("RN_AUDIO_TRAIN", "hip") == "torch":
@@ -112,7 +112,7 @@ def _audio_kernels(model):
         from . import audio
         _AUDIO_KERNELS.append(audio)
     a = _AUDIO_KERNELS[0]
-    return a if a.supported(model) and any(p.requires_grad for p in model.audio_net.parameters()) else None
+    return a if a.supported(model) and (not need_grad or any(p.requires_grad for p in model.audio_net.parameters())) else None
 
 
 def _mlp_kernels():
@@ -222,9 +222,13 @@ class NeRFNetwork(NeRFRenderer):
             a = self.embedding(a).transpose(-1, -2).contiguous()
         # training on the GPU: forward and backward of both audio nets as two kernels each (radnerf/audio.py) instead of
         # ~150 launches of tiny convolutions; RN_AUDIO_TRAIN=torch keeps the nn.Module path (the parity test compares them)
-        if a.is_cuda and torch.is_grad_enabled() and not self.emb and a.dtype == torch.float32 and \
-                not torch.is_autocast_enabled() and _audio_kernels(self) is not None:
-            return _audio_kernels(self).encode_windows_train(self, a)
+        if a.is_cuda and not self.emb and a.dtype == torch.float32 and not torch.is_autocast_enabled():
+            if torch.is_grad_enabled():
+                if _audio_kernels(self) is not None:
+                    return _audio_kernels(self).encode_windows_train(self, a)
+            elif _audio_kernels(self, need_grad=False) is not None:
+                # no gradient wanted (the occupancy refresh draws a random window every 16 training steps): the forward kernels
+                return _audio_kernels(self, need_grad=False).encode_windows(self, a)
         enc_a = self.audio_net(a)
         if self.att > 0:
             enc_a = self.audio_att_net(enc_a.unsqueeze(0))
