@@ -57,3 +57,34 @@ def test_no_oracle_or_cpu_fallback_in_product_tree():
                 if re.search(r"pyoracle|radnerf_oracle|libradnerf_oracle|orc_\w+\(", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_round2_entry_points_refuse_bad_arguments(hiplib):
+    """The argument checks of the training-side entry points run before anything touches a GPU: unsupported shapes and null
+    pointers come back as RN_ERR_INVALID_ARG with a message (no launch, no CPU fallback)."""
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    lib.rn_last_error.restype = ctypes.c_char_p
+    c_u32, c_p, c_f = ctypes.c_uint32, ctypes.c_void_p, ctypes.c_float
+
+    def err():
+        return lib.rn_last_error().decode()
+    lib.rn_mlp64_image_floats.restype = ctypes.c_size_t
+    lib.rn_mlp64_image_floats.argtypes = [c_u32, c_u32, c_u32]
+    assert lib.rn_mlp64_image_floats(96, 2, 3) > 0 and lib.rn_mlp64_image_floats(65, 65, 3) > 0 and lib.rn_mlp64_image_floats(84, 3, 2) > 0
+    assert lib.rn_mlp64_image_floats(128, 2, 3) == 0 and lib.rn_mlp64_image_floats(65, 7, 3) == 0 and lib.rn_mlp64_image_floats(65, 65, 4) == 0
+    lib.rn_mlp64_pack.argtypes = [c_p, c_u32, c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p]
+    assert lib.rn_mlp64_pack(None, 128, None, None, 128, 2, 3, None, None) != 0 and "unsupported shape" in err()
+    assert lib.rn_mlp64_pack(None, 32, None, None, 64, 2, 3, None, None) != 0 and "ld0" in err()
+    lib.rn_mlp64_forward.argtypes = [c_p, c_u32, c_p, c_p, c_u32, c_u32, c_u32, c_p, c_p, c_p, c_p]
+    assert lib.rn_mlp64_forward(None, 0, None, None, 65, 65, 3, None, None, None, None) == 0        # M = 0: nothing to do
+    assert lib.rn_mlp64_forward(None, 64, None, None, 65, 65, 3, None, None, None, None) != 0 and "null pointer" in err()
+    lib.rn_adam_step.argtypes = [c_p, c_u32, c_f, c_f, c_f, c_p, c_p, c_p]
+    assert lib.rn_adam_step(None, 0, 0.9, 0.99, 1e-15, None, None, None) != 0 and "step counter" in err()
+    lib.rn_train_loss.argtypes = [c_p] * 6 + [c_u32] + [c_p] * 5
+    assert lib.rn_train_loss(None, None, None, None, None, None, 0, None, None, None, None, None) != 0 and "N must be positive" in err()
+    lib.rn_head_mid_forward.argtypes = [c_p, c_p, c_u32, c_u32, c_p, c_p, c_p]
+    assert lib.rn_head_mid_forward(None, None, 10, 16, None, None, None) != 0 and "null pointer" in err()
+    lib.rn_audio_encode_windows_backward.argtypes = [c_p, c_p, c_u32, c_p, c_p, c_p, c_p, c_p]
+    assert lib.rn_audio_encode_windows_backward(None, None, 1, None, None, None, None, None) != 0 and "null weights" in err()
+    lib.rn_march_rays_train_budget.argtypes = [c_p, c_p, c_p, c_f, c_f] + [c_u32] * 5 + [c_p] * 11
+    assert lib.rn_march_rays_train_budget(None, None, None, 1.0, 0.0, 16, 64, 1, 128, 1000, *([None] * 11)) != 0 and "null pointer" in err()
