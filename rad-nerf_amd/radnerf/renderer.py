@@ -267,7 +267,13 @@ class NeRFRenderer(nn.Module):
         enc_a = self._audio_code(auds)
         ind_code = None
         if self.individual_dim > 0:
-            ind_code = self.individual_codes[index if self.training else 0]
+            if self.training and not isinstance(index, int):
+                # index_select = the same rows as individual_codes[index] (nerf/renderer.py:199); its backward is one index_add
+                # instead of index_put's sort + segmented scatter (5 launches for a one-element index)
+                idx = index if torch.is_tensor(index) else torch.as_tensor(list(index), dtype=torch.long, device=self.individual_codes.device)
+                ind_code = torch.index_select(self.individual_codes, 0, idx.reshape(-1).long())
+            else:
+                ind_code = self.individual_codes[index if self.training else 0]
 
         results = {}
         if self.training:
