@@ -393,9 +393,14 @@ def main():
             # matrix-core roof is the closer (binding) one; on the 16-bit matrix cores the contraction is ~16x cheaper and
             # the gathers bind.  `bound` names the binding roof, the other view rides along.
             tkey = {"f32": "nerf_fused", "f16": "nerf_fused_h16", "f32x2": "nerf_fused_x2"}[args.mlp]
-            common = dict(traffic=fpr.measured_traffic(tkey),
+            # bytes per launch WITH work from the counter passes, spread over this run's launches (some of which are the
+            # zero-sample launches behind the end of the loop)
+            t_work = fpr.measured_traffic(tkey, "hbm_bytes_per_launch_with_work")
+            traffic = t_work * iters_timed / fused_launches if t_work else fpr.measured_traffic(tkey)
+            common = dict(traffic=traffic,
                           traffic_source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile "
-                                         "run of this command (static in this line, not measured in this run)",
+                                         "run of this command (static in this line, not measured in this run): bytes per launch with "
+                                         "work x this run's share of launches with work",
                           launches=fused_launches, avg_launch_ms=fused_ms / fused_launches,
                           share_of_step=fused_ms / (elapsed * 1e3 * timed_frac), launches_with_work=iters_timed,
                           avg_launch_ms_with_work=sum(fused_durs[:iters_timed]) / max(iters_timed, 1),

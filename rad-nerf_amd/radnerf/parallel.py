@@ -97,13 +97,13 @@ class _Bookkeeping:
         return live / max(len(steps), 1), slots / max(len(steps), 1)
 
     @staticmethod
-    def measured_traffic(key):
+    def measured_traffic(key, field="hbm_bytes_per_launch"):
         """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), else None."""
         p = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles",
                          "traffic.json")
         if os.path.exists(p):
             try:
-                return json.load(open(p)).get(key, {}).get("hbm_bytes_per_launch")
+                return json.load(open(p)).get(key, {}).get(field)
             except Exception:
                 return None
         return None

@@ -46,10 +46,15 @@ def pairs(res, fetch, write):
         if not fv or not wv:
             continue
         f_kib, w_kib = sum(fv) / len(fv), sum(wv) / len(wv)
-        res[key] = dict(launches_profiled=len(fv), fetch_size_kib_per_launch_raw=f_kib, write_size_kib_per_launch=w_kib,
-                        hbm_bytes_per_launch=(2.0 * f_kib + w_kib) * 1024.0,
+        # launches with work: a zero-sample launch of the frame loop exits before it stages its weights (< 64 KiB fetched)
+        work = sum(1 for v in fv if v >= 64.0)
+        res[key] = dict(launches_profiled=len(fv), launches_with_work=work, fetch_size_kib_per_launch_raw=f_kib,
+                        write_size_kib_per_launch=w_kib, hbm_bytes_per_launch=(2.0 * f_kib + w_kib) * 1024.0,
+                        hbm_bytes_per_launch_with_work=(2.0 * sum(fv) + sum(wv)) * 1024.0 / max(work, 1),
                         hbm_bytes_per_launch_uncorrected=(f_kib + w_kib) * 1024.0,
-                        note="mean over every launch of the kernel in the profiled bench run (incl. zero-sample launches)")
+                        note="hbm_bytes_per_launch: mean over every launch of the kernel in the profiled bench run (incl. zero-sample "
+                             "launches, whose share depends on the run's warm-up / timed mix); _with_work: the same bytes over the "
+                             "launches that had samples")
 
 
 if __name__ == "__main__":
