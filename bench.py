@@ -395,8 +395,10 @@ def main():
             tkey = {"f32": "nerf_fused", "f16": "nerf_fused_h16", "f32x2": "nerf_fused_x2"}[args.mlp]
             # bytes per launch WITH work from the counter passes, spread over this run's launches (some of which are the
             # zero-sample launches behind the end of the loop)
-            t_work = fpr.measured_traffic(tkey, "hbm_bytes_per_launch_with_work")
-            traffic = t_work * iters_timed / fused_launches if t_work else fpr.measured_traffic(tkey)
+            # (the passes were taken on config[1] itself -- 512x512, hash19, regime B -- and describe only that workload)
+            profiled = args.grid == "hash19" and size == 512 and not tile and args.regime == "B"
+            t_work = fpr.measured_traffic(tkey, "hbm_bytes_per_launch_with_work") if profiled else None
+            traffic = t_work * iters_timed / fused_launches if t_work else (fpr.measured_traffic(tkey) if profiled else None)
             common = dict(traffic=traffic,
                           traffic_source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile "
                                          "run of this command (static in this line, not measured in this run): bytes per launch with "
