@@ -364,6 +364,11 @@ typedef struct {
 } rn_adam_tensor_t;
 int rn_adam_step(const rn_adam_tensor_t *tensors, uint32_t count, float beta1, float beta2, float eps, int32_t *step, float *corr,
                  rn_stream_t stream);
+/* The same with the learning rates read from device memory at run time (lr_dev [count] floats, one per tensor; NULL = the
+ * `lr` fields): a launch captured in a hipGraph then follows the reference's schedule (main.py:219: LambdaLR over the
+ * optimizer's param_groups) -- the host refreshes lr_dev between replays instead of re-capturing. */
+int rn_adam_step_lr(const rn_adam_tensor_t *tensors, uint32_t count, float beta1, float beta2, float eps, int32_t *step, float *corr,
+                    const float *lr_dev, rn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,8 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
     p = p - step_size * (m / denom);
 }
 
-__global__ void __launch_bounds__(kAdamBlock) k_adam(AdamArgs a, float beta1, float beta2, float eps, const float *__restrict__ corr) {
+__global__ void __launch_bounds__(kAdamBlock) k_adam(AdamArgs a, float beta1, float beta2, float eps, const float *__restrict__ corr,
+                                                     const float *__restrict__ lr_dev) {
     // which tensor does this workgroup belong to?  (<= 48 entries: a scan in scalar registers)
     uint32_t t = 0;
     while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) t++;
@@ -51,7 +52,9 @@ __global__ void __launch_bounds__(kAdamBlock) k_adam(AdamArgs a, float beta1, fl
     const uint32_t n = a.n[t];
     if (base >= n) return;
     const float bc1 = corr[0], bc2_sqrt = corr[1];
-    const float step_size = a.lr[t] / bc1;
+    // lr_dev (nullable): the tensors' learning rates in device memory, read at run time -- a captured launch then follows a
+    // learning-rate schedule (main.py:219 LambdaLR) instead of replaying the value it was captured with
+    const float step_size = (lr_dev ? lr_dev[t] : a.lr[t]) / bc1;
     float *p = a.p[t] + base, *m = a.m[t] + base, *v = a.v[t] + base;
     const float *g = a.g[t] + base;
     if (base + 4 <= n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -205,6 +208,11 @@ int rn_train_loss(const float *pred, const float *target, const float *weights_s
 
 int rn_adam_step(const rn_adam_tensor_t *tensors, uint32_t count, float beta1, float beta2, float eps, int32_t *step, float *corr,
                  rn_stream_t stream) {
+    return rn_adam_step_lr(tensors, count, beta1, beta2, eps, step, corr, nullptr, stream);
+}
+
+int rn_adam_step_lr(const rn_adam_tensor_t *tensors, uint32_t count, float beta1, float beta2, float eps, int32_t *step, float *corr,
+                    const float *lr_dev, rn_stream_t stream) {
     RN_REQUIRE(tensors || count == 0, "adam_step: null tensor list");
     RN_REQUIRE(step && corr, "adam_step: step counter (int32) and a 2-float scratch are required");
     hipStream_t s = as_stream(stream);
@@ -222,7 +230,7 @@ int rn_adam_step(const rn_adam_tensor_t *tensors, uint32_t count, float beta1, f
         }
         a.first_block[k] = blocks;
         a.count = k;
-        if (blocks) hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(kAdamBlock), 0, s, a, beta1, beta2, eps, corr);
+        if (blocks) hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(kAdamBlock), 0, s, a, beta1, beta2, eps, corr, lr_dev ? lr_dev + at : nullptr);
     }
     return check_launch("adam_step");
 }

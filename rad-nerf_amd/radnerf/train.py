@@ -34,6 +34,11 @@ class HipAdam:
     torch.optim.Adam's format, so reference checkpoints carry over); the step counter lives on the device, so a step is
     capturable in a hipGraph."""
 
+    # what torch.optim.Adam keeps in every param_group (torch/optim/adam.py): a state dict written here loads into the
+    # reference's torch.optim.Adam (nerf/utils.py:1302-1426 saves / restores optimizer.state_dict())
+    _TORCH_ADAM_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                                fused=None, decoupled_weight_decay=False)
+
     def __init__(self, params, betas=(0.9, 0.99), eps=1e-15):
         import ctypes as C
         import radnerf_hip as hip
@@ -43,8 +48,8 @@ class HipAdam:
             _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                         ("numel", C.c_uint32), ("lr", C.c_float)]
         self._T = AdamTensorT
-        fn = hip._lib.rn_adam_step
-        fn.argtypes = [C.POINTER(AdamTensorT), C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn = hip._lib.rn_adam_step_lr
+        fn.argtypes = [C.POINTER(AdamTensorT), C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         fn.restype = C.c_int
         self.param_groups = []
         for g in params:
@@ -54,14 +59,23 @@ class HipAdam:
                 raise ValueError("HipAdam: weight decay is not part of the reference's configuration (main.py:204) and not implemented")
             g.setdefault("betas", betas)
             g.setdefault("eps", eps)
+            for k, v in self._TORCH_ADAM_DEFAULTS.items():
+                g.setdefault(k, v)
+            g.setdefault("initial_lr", g["lr"])      # what torch's LR schedulers look for (LambdaLR, main.py:219)
             self.param_groups.append(g)
         self.betas, self.eps = betas, eps
+        self.defaults = dict(lr=self.param_groups[0]["lr"], betas=betas, eps=eps, **self._TORCH_ADAM_DEFAULTS)
         dev = self.param_groups[0]["params"][0].device
         self.state = {p: {"exp_avg": torch.zeros_like(p, memory_format=torch.contiguous_format),
                           "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
                       for g in self.param_groups for p in g["params"]}
         self._step = torch.zeros(1, dtype=torch.int32, device=dev)
         self._corr = torch.zeros(2, dtype=torch.float32, device=dev)
+        n = sum(len(g["params"]) for g in self.param_groups)
+        # learning rates live on the device, one per updated tensor in the order of the last step(): a captured step reads
+        # them at run time, so a schedule that rewrites param_groups[i]["lr"] is followed by every replay (refresh_lr())
+        self._lr_dev = torch.zeros(max(n, 1), dtype=torch.float32, device=dev)
+        self._lr_groups, self._lr_sent, self._written = [], None, []
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -71,13 +85,23 @@ class HipAdam:
                 elif p.grad is not None:
                     p.grad.zero_()
 
+    def refresh_lr(self):
+        """Upload the groups' current learning rates when they changed since the last upload (call outside a capture; a
+        GraphedTrainer does so before every replay)."""
+        lrs = [float(self.param_groups[gi]["lr"]) for gi in self._lr_groups]
+        if lrs and lrs != self._lr_sent:
+            self._lr_dev[:len(lrs)].copy_(torch.tensor(lrs, dtype=torch.float32))
+            self._lr_sent = lrs
+
     @torch.no_grad()
     def step(self):
-        entries, keep = [], []
-        for g in self.param_groups:
+        entries, keep, written, groups = [], [], [], []
+        for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
                 if p.grad is None:
                     continue
+                written.append(p)
+                groups.append(gi)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous() or p.dtype != torch.float32 or grad.dtype != torch.float32:
                     raise RuntimeError("HipAdam: parameters and gradients must be contiguous fp32")
@@ -87,8 +111,16 @@ class HipAdam:
         arr = (self._T * max(len(entries), 1))()
         for i, e in enumerate(entries):
             arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq, arr[i].numel, arr[i].lr = e
-        self._hip.call("rn_adam_step", arr, len(entries), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                       self._hip.ptr(self._step), self._hip.ptr(self._corr), self._hip.stream())
+        if groups != self._lr_groups:
+            self._lr_groups, self._lr_sent = groups, None
+        if not torch.cuda.is_current_stream_capturing():
+            self.refresh_lr()
+        elif self._lr_sent is None:
+            raise RuntimeError("HipAdam: take one eager step (or call refresh_lr()) before capturing a step in a graph")
+        self._hip.call("rn_adam_step_lr", arr, len(entries), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                       self._hip.ptr(self._step), self._hip.ptr(self._corr), self._hip.ptr(self._lr_dev), self._hip.stream())
+        self._written = written
+        self._hip.mark_written(written)      # the kernel wrote through raw pointers: caches keyed on tensor versions must see it
 
     def state_dict(self):
         """torch.optim.Adam's layout: state by running parameter index, one `step` per tensor."""
@@ -334,7 +366,11 @@ class GraphedTrainer(Trainer):
             self._static["index"].copy_(torch.tensor(v, dtype=torch.long))
             self._static_index = list(v)
         self._amb_weight.fill_(min(self.global_step / self.iters, 1.0) * self.lambda_amb)
+        if isinstance(self.optimizer, HipAdam):
+            self.optimizer.refresh_lr()             # a schedule may have rewritten param_groups[i]["lr"] since the last step
         self._graph.replay()
+        if isinstance(self.optimizer, HipAdam):     # the replayed update went through raw pointers (see HipAdam.step)
+            self.optimizer._hip.mark_written(self.optimizer._written)
         m.step_counter[m.local_step % 16].copy_(self._counter)
         m.local_step += 1
         self.replays += 1

@@ -233,6 +233,15 @@ def ptr(t, dtype=None):
     return t.data_ptr()
 
 
+def mark_written(tensors):
+    """Tell PyTorch that kernels wrote these tensors through raw pointers (the one-kernel Adam update, a replayed hipGraph):
+    bump their version counters, which is what caches of derived data key on (FusedState's packed weight images,
+    GridEncoder.half_table) -- otherwise they would keep serving the values of the first pack."""
+    ts = [t for t in tensors if t is not None]
+    if ts:
+        torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+
+
 def aligned(t, nbytes=16):
     """Contiguous tensor whose base address is `nbytes`-aligned (vector loads in the kernels)."""
     t = t.contiguous()

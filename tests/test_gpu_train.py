@@ -410,3 +410,110 @@ def test_train_step_with_glue_kernels_equals_the_torch_step(hiplib, monkeypatch)
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_fused_engine_sees_weights_updated_by_the_optimizer(hiplib, graphed):
+    """HipAdam and a replayed hipGraph write the parameters through raw pointers.  The fused engine's packed weight images (and
+    GridEncoder.half_table) are caches keyed on tensor versions, so the update must bump them: after N training steps the
+    occupancy refresh's density query (fused.density_forward, what update_extra_state runs) must use the CURRENT weights."""
+    from radnerf import fused
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream, Trainer
+    scene = _scene(64, torso=False, smooth_lips=False)
+    stream = SyntheticTrainStream(scene, n_rays=2048)
+    m = scene.model
+    f = scene.frame(0)
+    enc_a = m.encode_audio(f["auds"]).detach()
+    pts = (torch.rand(4096, 3, device="cuda") - 0.5) * 0.8
+    m.eval()
+    with torch.no_grad():
+        first = fused.density_forward(m, pts, enc_a, f["eye"]).clone()        # packs the initial weights
+        half0 = m.encoder.half_table().clone()
+    trainer = (GraphedTrainer if graphed else Trainer)(m, scene.opt, lr=5e-2, lr_net=5e-2, update_extra_interval=0)
+    for _ in range(4):
+        trainer.step(stream.batch())
+    if graphed:
+        m.mean_count = int(m.step_counter[:4, 0].float().mean().item() * 1.2)
+        for _ in range(4):
+            trainer.step(stream.batch())
+        assert trainer.replays == 4
+    m.eval()
+    with torch.no_grad():
+        now = fused.density_forward(m, pts, enc_a, f["eye"])
+        ref = m.density(pts, enc_a, f["eye"])["sigma"]
+        half1 = m.encoder.half_table()
+    assert float((now - first).abs().max()) > 1e-3 * float(first.abs().max())      # the weights did move
+    np.testing.assert_allclose(now.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=1e-6)
+    assert torch.equal(half1, m.encoder.embeddings.detach().half()) and not torch.equal(half0, half1)
+
+
+def test_hip_adam_captured_step_follows_lr_changes(hiplib):
+    """The Adam launch reads its learning rates from device memory (rn_adam_step_lr): a step captured in a hipGraph follows
+    changes of optimizer.param_groups[i]['lr'] between replays (the reference decays it with LambdaLR, main.py:219), like
+    torch.optim.Adam stepping eagerly; the state dict carries torch.optim.Adam's keys."""
+    from radnerf.train import HipAdam
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(4099,), (64, 96), (5,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda", generator=gen)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:1], "lr": 5e-3}, {"params": ps[1:], "lr": 5e-4, "weight_decay": 0}]
+    oa = HipAdam(groups(pa), betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-15)
+    for a, b in zip(pa, pb):
+        a.grad = torch.randn(a.shape, device="cuda", generator=gen)
+        b.grad = a.grad.clone()
+    oa.step(), ob.step()                                    # eager: uploads the learning rates
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        oa.step()
+    ob.step()                                               # the capture pass is not a step; replay it once to stay in sync
+    graph.replay()
+    for i in range(5):
+        for a, b in zip(pa, pb):
+            a.grad.copy_(torch.randn(a.shape, device="cuda", generator=gen))
+            b.grad.copy_(a.grad)
+        for o in (oa, ob):
+            for g in o.param_groups:
+                g["lr"] = g["lr"] * 0.5
+        oa.refresh_lr()
+        graph.replay()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max())
+    sd = oa.state_dict()
+    assert all(k in g for g in sd["param_groups"] for k in ("weight_decay", "amsgrad", "maximize", "betas", "eps", "lr"))
+    fresh = torch.optim.Adam(groups([torch.nn.Parameter(p.detach().clone()) for p in pa]), betas=(0.9, 0.99), eps=1e-15)
+    fresh.load_state_dict(sd)
+    assert fresh.param_groups[0]["lr"] == oa.param_groups[0]["lr"]
+
+
+def test_graphed_trainer_follows_a_learning_rate_schedule(hiplib):
+    """GraphedTrainer refreshes the device-side learning rates before every replay: with a decaying schedule its loss curve is
+    the eager Trainer's (2e-3: atomics reorder sums), and it is NOT the curve of a constant learning rate."""
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream, Trainer
+    curves = {}
+    for kind in ("eager", "graph", "graph_const"):
+        torch.manual_seed(21)
+        scene = _scene(64, torso=False, smooth_lips=False)
+        stream = SyntheticTrainStream(scene, n_rays=2048, seed=4)
+        m = scene.model
+        with torch.no_grad():
+            m.color_net.net[-1].weight.add_(0.5 * torch.randn_like(m.color_net.net[-1].weight))
+        trainer = (Trainer if kind == "eager" else GraphedTrainer)(m, scene.opt, lr_net=5e-3, update_extra_interval=0)
+        losses = []
+        for i in range(15):
+            if i == 3:
+                m.mean_count = 40000
+                torch.manual_seed(22)
+            if kind != "graph_const":
+                for g in trainer.optimizer.param_groups:
+                    g["lr"] = g["initial_lr"] * 0.1 ** (i / 5.0)
+            losses.append(float(trainer.step(stream.batch())))
+        curves[kind] = np.array(losses)
+        if kind != "eager":
+            assert trainer.captures == 1 and trainer.replays == 12
+    print("lr schedule curves", {k: v.tolist() for k, v in curves.items()})
+    np.testing.assert_allclose(curves["graph"], curves["eager"], rtol=1e-2, atol=1e-7)
+    gap = np.abs(curves["graph_const"] - curves["graph"]) / curves["graph"]
+    assert gap.max() > 5 * (np.abs(curves["graph"] - curves["eager"]) / curves["eager"]).max() and gap.max() > 3e-2, gap
