@@ -1,0 +1,1115 @@
+// rn_train_head.hip -- the per-sample network of the TRAINING step as one forward and one backward kernel (gfx950).
+//
+// C ABI: include/radnerf_train.h.  What is computed: NeRFNetwork.forward (nerf/network.py:222-283) and its autograd as
+// Trainer.train_step runs it on the ~60 k samples of a 4096-ray batch (nerf/utils.py:718-806, nerf/renderer.py:206-223).
+// How (MI355X-first; the inference kernel's machine, rn_fused.hip, made differentiable):
+//
+//  * k_train_fwd: one wavefront owns 32 samples; lane half h gathers level 2 r + h in round r, the two features are the B
+//    operands of two v_mfma_f32_32x32x2_f32 steps of both first layers that read enc_x; a layer's accumulators (sample on
+//    the lane, output row on the register index) ARE the next layer's B operand.  Everything the backward pass needs is
+//    stored in that register layout -- a "native tile" is [register][64 lanes] floats, i.e. every store is a coalesced 256-B
+//    row: the post-ReLU hidden activations of the five hidden layers, geo_feat, the grid features (they are operands of the
+//    weight gradients) and d enc_w / d ambient of the 2-D grid.
+//  * k_train_bwd: the same tile walked back.  dX = W^T dY is a forward layer with the transposed weight image, ReLU masks
+//    come from the saved activations, tanh' / sigmoid' / trunc_exp' from the saved outputs.  The gradient with respect to
+//    the ambient coordinates (sum over levels of g * dy_dx, gridencoder.cu:342-368) is taken inside the tile.  Feature
+//    gradients of both grids leave level-major ([L, M, 2]: one coalesced 256-B row per level and lane half).
+//  * k_train_wgrad: dW = dZ X^T for all eight layers in one launch.  A workgroup stages a 32-sample tile of both operands
+//    transposed in LDS ([feature][sample]); the sample index is the k of the MFMA; accumulators stay in registers over the
+//    workgroup's tiles; per-workgroup partial sums are folded by k_train_wreduce into the nn.Linear layout.  The columns of
+//    the per-call constants (audio code, eye, individual code) ride along as one more feature that is 1 for every sample:
+//    its gradient column is the bias gradient, from which k_train_const derives the constants' and their columns' gradients.
+//  * k_grid_scatter: table gradient.  Float atomics run at the memory side, one request per touched 64-B line per
+//    instruction (MI355X_MICROARCH.md, "Global float atomics"), so a workgroup first sums its 128 samples x 2^D corners of
+//    one level in an LDS table keyed by the 64-B LINE of the gradient table (8 rows x 2 channels = 16 floats per slot; the
+//    two x-neighbours of a corner pair share a line 7 times out of 8, on hashed levels too: the x prime is 1) and then
+//    issues the 16 floats of a slot from 16 adjacent lanes -- one request per touched line instead of one per row.
+#include "rn_fused_dev.h"
+
+#include <stdlib.h>
+
+#include "../../include/radnerf_train.h"
+
+namespace rn {
+namespace th {
+
+constexpr int kStep = 128;   // floats per MFMA step of a 64-row layer: [2 h][32 j][2 row tiles]
+// ---- forward image (the inference kernel's layout) ------------------------------------------------------------------
+constexpr int F_A0 = 0;                    // ambient L0, enc_x part : 16 steps
+constexpr int F_A1 = F_A0 + 16 * kStep;    // ambient L1            : 32 steps
+constexpr int F_A2 = F_A1 + 32 * kStep;    // ambient L2 (VALU)     : [2 out][2 h][32]
+constexpr int F_S0 = F_A2 + 128;           // sigma L0 (enc_x|enc_w): 32 steps
+constexpr int F_S1 = F_S0 + 32 * kStep;    // sigma L1              : 32 steps
+constexpr int F_S2 = F_S1 + 32 * kStep;    // sigma L2 rows 1..64   : 32 steps
+constexpr int F_S2R = F_S2 + 32 * kStep;   // sigma L2 row 0 (VALU) : [2 h][32]
+constexpr int F_C0 = F_S2R + 64;           // color L0 (sh | geo)   : 8 + 32 steps
+constexpr int F_C1 = F_C0 + 40 * kStep;    // color L1 (VALU)       : [3 out][2 h][32]
+constexpr int kFwd = F_C1 + 192;           // 23936 floats
+// ---- transposed image: T[s][h][j][rt] = W[kmap(s, h)][column(32 rt + j)] ---------------------------------------------
+constexpr int T_C0 = 0;                    // d geo_feat   = W_col0[:, 16:80]^T dZ_c0
+constexpr int T_S2 = T_C0 + 32 * kStep;    // d h_s1       = W_sig2[1:65]^T d geo_feat
+constexpr int T_S1 = T_S2 + 32 * kStep;
+constexpr int T_S0 = T_S1 + 32 * kStep;    // d [enc_x | enc_w] = W_sig0[:, 0:64]^T dZ_s0, output rows in gather order (below)
+constexpr int T_A1 = T_S0 + 32 * kStep;
+constexpr int T_A0 = T_A1 + 32 * kStep;    // d enc_x += W_amb0[:, 0:32]^T dZ_a0 : 32 steps x [2 h][32 j]
+constexpr int N_C1 = T_A0 + 32 * 64;       // narrow rows again: [3][2 h][32]
+constexpr int N_S2R = N_C1 + 192;          // [2 h][32]
+constexpr int N_A2 = N_S2R + 64;           // [2][2 h][32]
+constexpr int kBwd = N_A2 + 128;           // 22912 floats
+constexpr int kBias = 192;
+constexpr int kImage = kFwd + kBwd + kBias;
+
+// Output row j of a 32-row tile sits in register r of lane half hh with rowmap(r, hh) == j.  The grid-feature gradients want
+// register 2 q + c of lane half hh to be (level 2 q + hh, channel c), the layout the forward gathers in: feature 4 q + 2 hh + c.
+__host__ __device__ constexpr int gather_feature(int j) {
+    const int hh = (j >> 2) & 1, r = (j & 3) + 4 * (j >> 3);
+    return 4 * (r >> 1) + 2 * hh + (r & 1);
+}
+
+__global__ void __launch_bounds__(256) k_train_pack(RawW w, const float *__restrict__ enc_a, const float *__restrict__ eye,
+                                                    const float *__restrict__ ind_code, float *__restrict__ image) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kImage) return;
+    const int ldA0 = 32 + (int)w.audio_dim, ldS0 = 64 + (int)w.has_eye, ldC0 = 80 + (int)w.ind_dim;
+    float v;
+    auto mfma_elem = [&](int q, const float *src, int ld, int kind) -> float {
+        const int s = q / kStep, rem = q % kStep;
+        const int h = rem / 64, j = (rem % 64) / 2, rt = rem % 2;
+        const int row = 32 * rt + j;
+        int k;
+        if (kind == 3) k = 4 * (s >> 1) + 2 * h + (s & 1);       // gather rounds: half h holds level 2 (s / 2) + h
+        else if (kind == 1) k = kmap(s, h);                       // previous accumulators
+        else k = (s < 8) ? 2 * s + h : 16 + kmap(s - 8, h);      // color L0: sh pairs then geo accumulators
+        return src[row * ld + k];
+    };
+    auto valu_elem = [&](int q0, const float *src) -> float {    // [out][h][q], q = rt * 16 + r
+        const int o = q0 / 64, h = (q0 % 64) / 32, q = q0 % 32;
+        return src[o * 64 + 32 * (q >> 4) + rowmap(q & 15, h)];
+    };
+    auto t_elem = [&](int q, const float *src, int ld, int col0, bool gather) -> float {   // transposed 64-row layer
+        const int s = q / kStep, rem = q % kStep;
+        const int h = rem / 64, j = (rem % 64) / 2, rt = rem % 2;
+        const int col = gather ? 32 * rt + gather_feature(j) : 32 * rt + j;
+        return src[kmap(s, h) * ld + col0 + col];
+    };
+    if (e < kFwd) {
+        if (e < F_A1) v = mfma_elem(e - F_A0, w.amb_w0, ldA0, 3);
+        else if (e < F_A2) v = mfma_elem(e - F_A1, w.amb_w1, 64, 1);
+        else if (e < F_S0) v = valu_elem(e - F_A2, w.amb_w2);
+        else if (e < F_S1) v = mfma_elem(e - F_S0, w.sig_w0, ldS0, 3);
+        else if (e < F_S2) v = mfma_elem(e - F_S1, w.sig_w1, 64, 1);
+        else if (e < F_S2R) v = mfma_elem(e - F_S2, w.sig_w2 + 64, 64, 1);   // rows 1..64 = geo_feat
+        else if (e < F_C0) v = valu_elem(e - F_S2R, w.sig_w2);               // row 0 = sigma
+        else if (e < F_C1) v = mfma_elem(e - F_C0, w.col_w0, ldC0, 2);
+        else v = valu_elem(e - F_C1, w.col_w1);
+    } else if (e < kFwd + kBwd) {
+        const int t = e - kFwd;
+        if (t < T_S2) v = t_elem(t - T_C0, w.col_w0, ldC0, 16, false);
+        else if (t < T_S1) v = t_elem(t - T_S2, w.sig_w2 + 64, 64, 0, false);
+        else if (t < T_S0) v = t_elem(t - T_S1, w.sig_w1, 64, 0, false);
+        else if (t < T_A1) v = t_elem(t - T_S0, w.sig_w0, ldS0, 0, true);
+        else if (t < T_A0) v = t_elem(t - T_A1, w.amb_w1, 64, 0, false);
+        else if (t < N_C1) {
+            const int q = t - T_A0, s = q / 64, rem = q % 64, h = rem / 32, j = rem % 32;
+            v = w.amb_w0[kmap(s, h) * ldA0 + gather_feature(j)];
+        } else if (t < N_S2R) v = valu_elem(t - N_C1, w.col_w1);
+        else if (t < N_A2) v = valu_elem(t - N_S2R, w.sig_w2);
+        else v = valu_elem(t - N_A2, w.amb_w2);
+    } else {   // first-layer biases of the per-call constants (nerf/network.py:236, 262, 274)
+        const int t = e - kFwd - kBwd, row = t & 63;
+        float acc = 0.0f;
+        if (t < 64) {
+            const float *r = w.amb_w0 + row * ldA0 + 32;
+            for (uint32_t a = 0; a < w.audio_dim; a++) acc += r[a] * enc_a[a];
+        } else if (t < 128) {
+            if (w.has_eye) acc = w.sig_w0[row * ldS0 + 64] * eye[0];
+        } else {
+            const float *r = w.col_w0 + row * ldC0 + 80;
+            for (uint32_t c = 0; c < w.ind_dim; c++) acc += r[c] * ind_code[c];
+        }
+        v = acc;
+    }
+    image[e] = v;
+}
+
+// ---- workspace ----------------------------------------------------------------------------------------------------------
+// native tiles ([registers][64 lanes] floats per 32-sample tile) and per-sample rows, one contiguous region each
+struct Ws {
+    float *ex, *ew;          // grid features, 16 registers: register 2 q + c of half h = level 2 q + h, channel c
+    float *dw;               // d enc_w / d (normalised ambient coordinate), 32 registers: 4 q + 2 d + c of half h
+    float *sh;               // SH basis, 8 registers: register q of half h = sh[2 q + h]
+    float *ha0, *ha1, *hs0, *hs1, *geo, *hc0;        // 32 registers each
+    float *dza0, *dza1, *dzs0, *dzs1, *dgeo, *dzc0;  // pre-activation gradients (backward), 32 registers each
+    float *sraw;             // [M_pad] sigma_net output row 0
+    float *daraw, *dsraw, *dprec;   // [M_pad, 2], [M_pad], [M_pad, 3]: gradients of the narrow layers' outputs
+};
+constexpr uint32_t kTile16 = 16 * 64, kTile32 = 32 * 64, kTile8 = 8 * 64;
+constexpr uint32_t kWsPerTile = 2 * kTile16 + kTile32 + kTile8 + 12 * kTile32 + 32 * 7;
+
+__host__ __device__ inline Ws make_ws(float *base, uint32_t M) {
+    const size_t nt = (M + 31u) >> 5;
+    Ws w;
+    float *p = base;
+    w.ex = p; p += nt * kTile16;
+    w.ew = p; p += nt * kTile16;
+    w.dw = p; p += nt * kTile32;
+    w.sh = p; p += nt * kTile8;
+    w.ha0 = p; p += nt * kTile32;
+    w.ha1 = p; p += nt * kTile32;
+    w.hs0 = p; p += nt * kTile32;
+    w.hs1 = p; p += nt * kTile32;
+    w.geo = p; p += nt * kTile32;
+    w.hc0 = p; p += nt * kTile32;
+    w.dza0 = p; p += nt * kTile32;
+    w.dza1 = p; p += nt * kTile32;
+    w.dzs0 = p; p += nt * kTile32;
+    w.dzs1 = p; p += nt * kTile32;
+    w.dgeo = p; p += nt * kTile32;
+    w.dzc0 = p; p += nt * kTile32;
+    w.sraw = p; p += nt * 32;
+    w.daraw = p; p += nt * 64;
+    w.dsraw = p; p += nt * 32;
+    w.dprec = p; p += nt * 96;
+    return w;
+}
+
+// ---- MFMA helpers (32-sample tiles) ---------------------------------------------------------------------------------------
+struct Acc32 {
+    f32x16 v[2];
+};
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void acc_zero(Acc32 &a) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.v[rt][r] = 0.0f;
+}
+__device__ __forceinline__ void acc_bias(Acc32 &a, const float *bias64, int h) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias64 + 32 * rt + 8 * g + 4 * h);
+            a.v[rt][4 * g + 0] = b.x; a.v[rt][4 * g + 1] = b.y; a.v[rt][4 * g + 2] = b.z; a.v[rt][4 * g + 3] = b.w;
+        }
+}
+__device__ __forceinline__ void acc_relu(Acc32 &a) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.v[rt][r] = relu_bits(a.v[rt][r]);
+}
+__device__ __forceinline__ void step32(Acc32 &a, const float *wl, int s, int lane_off, float b) {
+    const float2 w = *reinterpret_cast<const float2 *>(wl + s * kStep + lane_off);
+    a.v[0] = mfma32(w.x, b, a.v[0]);
+    a.v[1] = mfma32(w.y, b, a.v[1]);
+}
+__device__ __forceinline__ void layer_from_acc(Acc32 &out, const Acc32 &in, const float *wl, int lane_off) {
+#pragma unroll
+    for (int s = 0; s < 32; s++) step32(out, wl, s, lane_off, in.v[s >> 4][s & 15]);
+}
+template <int NOUT>
+__device__ __forceinline__ void valu_out(const Acc32 &in, const float *wl, int h, float (&out)[NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) {
+        float p = 0.0f;
+        const float *wo = wl + (o * 2 + h) * 32;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const float4 w = *reinterpret_cast<const float4 *>(wo + 4 * g);
+            const int rt = g >> 2, r = (g & 3) * 4;
+            p = __builtin_fmaf(in.v[rt][r + 0], w.x, p);
+            p = __builtin_fmaf(in.v[rt][r + 1], w.y, p);
+            p = __builtin_fmaf(in.v[rt][r + 2], w.z, p);
+            p = __builtin_fmaf(in.v[rt][r + 3], w.w, p);
+        }
+        out[o] = p + __shfl_xor(p, 32, 64);
+    }
+}
+// g[k] += sum_o W[o][k] d[o] for the k's this lane holds (the transposed narrow layer)
+template <int NOUT>
+__device__ __forceinline__ void valu_out_T(Acc32 &g, const float *wl, int h, const float (&d)[NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) {
+        const float *wo = wl + (o * 2 + h) * 32;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float4 w = *reinterpret_cast<const float4 *>(wo + 4 * q);
+            const int rt = q >> 2, r = (q & 3) * 4;
+            g.v[rt][r + 0] = __builtin_fmaf(w.x, d[o], g.v[rt][r + 0]);
+            g.v[rt][r + 1] = __builtin_fmaf(w.y, d[o], g.v[rt][r + 1]);
+            g.v[rt][r + 2] = __builtin_fmaf(w.z, d[o], g.v[rt][r + 2]);
+            g.v[rt][r + 3] = __builtin_fmaf(w.w, d[o], g.v[rt][r + 3]);
+        }
+    }
+}
+__device__ __forceinline__ void tile_store(float *__restrict__ dst, const Acc32 &a, int lane) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[(rt * 16 + r) * 64 + lane] = a.v[rt][r];
+}
+// g = (saved activation > 0) ? g : 0, the saved tile read row by row
+__device__ __forceinline__ void relu_mask(Acc32 &g, const float *__restrict__ saved, int lane) {
+    float hv[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) hv[q] = saved[q * 64 + lane];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) g.v[rt][r] = hv[rt * 16 + r] > 0.0f ? g.v[rt][r] : 0.0f;
+}
+
+constexpr int kThreads = 512, kWaves = kThreads / kWave;   // two waves per SIMD: a 4096-ray step is ~1 tile per wave slot
+
+struct FwdParams {
+    const float *xyzs, *dirs;
+    uint32_t M;
+    const int32_t *m_dev;
+    GridArgs gx, gw;
+    const float *image;
+    float bound;
+    float *sigmas, *rgbs, *ambient, *ambient_abs, *xn, *wn;
+    float *ws;
+};
+
+__device__ __forceinline__ uint32_t live_count(uint32_t M, const int32_t *m_dev) {
+    if (!m_dev) return M;
+    const int32_t d = *m_dev;
+    return d <= 0 ? 0u : ((uint32_t)d < M ? (uint32_t)d : M);
+}
+
+__global__ void __launch_bounds__(kThreads) k_train_fwd(FwdParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kFwd + kBias];
+    __shared__ LevelPlan plan_x[16], plan_w[16];
+    const uint32_t M = live_count(p.M, p.m_dev);
+    const uint32_t n_tiles = (M + 31u) >> 5;
+    if (blockIdx.x * kWaves >= n_tiles) return;
+    for (int i = threadIdx.x; i < kFwd / 4; i += kThreads) reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.image)[i];
+    if (threadIdx.x < kBias) lds[kFwd + threadIdx.x] = p.image[kFwd + kBwd + threadIdx.x];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        const uint32_t ox = (uint32_t)p.gx.offsets[t], ow = (uint32_t)p.gw.offsets[t];
+        plan_x[t] = plan_level<3>(p.gx.lc.scale[t], p.gx.lc.resolution[t], ox, (uint32_t)p.gx.offsets[t + 1] - ox, p.gx.gridtype, 8u);
+        plan_w[t] = plan_level<2>(p.gw.lc.scale[t], p.gw.lc.resolution[t], ow, (uint32_t)p.gw.offsets[t + 1] - ow, p.gw.gridtype, 8u);
+    }
+    __syncthreads();
+    const Ws ws = make_ws(p.ws, p.M);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int lane_off = h * 64 + j * 2;
+    const float *bias_amb = lds + kFwd, *bias_sig = lds + kFwd + 64, *bias_col = lds + kFwd + 128;
+    const float *tx = static_cast<const float *>(p.gx.table), *tw = static_cast<const float *>(p.gw.table);
+
+    for (uint32_t tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += gridDim.x * kWaves) {
+        const uint32_t sample = tile * 32 + j;   // both lane halves work on the same 32 samples
+        const bool live = sample < M;
+        Acc32 a0, a1, a2;
+        acc_bias(a0, bias_amb, h);   // ambient L0, start = W0[:, 32:] enc_a
+        acc_bias(a2, bias_sig, h);   // sigma   L0, start = W0[:, 64] eye
+        // ---- xyz grid (gridencoder/grid.py:145-161)
+        {
+            float in[3] = {0.0f, 0.0f, 0.0f};
+            bool on = live;
+            if (live) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    in[d] = (p.xyzs[3 * (size_t)sample + d] + p.bound) / (2 * p.bound);
+                    on = on && !(in[d] < 0 || in[d] > 1);
+                }
+                if (h == 0) { p.xn[3 * (size_t)sample] = in[0]; p.xn[3 * (size_t)sample + 1] = in[1]; p.xn[3 * (size_t)sample + 2] = in[2]; }
+            }
+            float *ex = ws.ex + (size_t)tile * kTile16;
+            LevelFetch<float, 3, 2> f;
+#pragma unroll 1
+            for (int r = 0; r < 8; r++) {
+                float f0 = 0.0f, f1 = 0.0f;
+                if (on) {
+                    issue_planned<float, 3, 2, false, false>(tx, plan_x[2 * r + h], in, f);
+                    float res[2], dummy[1];
+                    blend_level<float, 3, 2, false>(f, 0.0f, res, dummy);
+                    f0 = res[0];
+                    f1 = res[1];
+                }
+                step32(a0, lds + F_A0, 2 * r, lane_off, f0);
+                step32(a2, lds + F_S0, 2 * r, lane_off, f0);
+                step32(a0, lds + F_A0, 2 * r + 1, lane_off, f1);
+                step32(a2, lds + F_S0, 2 * r + 1, lane_off, f1);
+                ex[(2 * r) * 64 + lane] = f0;
+                ex[(2 * r + 1) * 64 + lane] = f1;
+            }
+        }
+        // ---- ambient net: [enc_x | enc_a] 96 -> 64 -> 64 -> 2, tanh
+        acc_relu(a0);
+        tile_store(ws.ha0 + (size_t)tile * kTile32, a0, lane);
+        acc_zero(a1);
+        layer_from_acc(a1, a0, lds + F_A1, lane_off);
+        acc_relu(a1);
+        tile_store(ws.ha1 + (size_t)tile * kTile32, a1, lane);
+        float amb[2];
+        valu_out<2>(a1, lds + F_A2, h, amb);
+        amb[0] = tanhf(amb[0]);
+        amb[1] = tanhf(amb[1]);
+        // ---- ambient grid (+ d enc_w / d input): enc_w -> sigma L0 steps 16..31
+        {
+            float in[2] = {(amb[0] + 1.0f) / 2.0f, (amb[1] + 1.0f) / 2.0f};
+            const bool on = live && !(in[0] < 0 || in[0] > 1 || in[1] < 0 || in[1] > 1);
+            if (live && h == 0) {
+                p.ambient[2 * (size_t)sample] = amb[0];
+                p.ambient[2 * (size_t)sample + 1] = amb[1];
+                if (p.ambient_abs) p.ambient_abs[sample] = fabsf(amb[0]) + fabsf(amb[1]);
+                p.wn[2 * (size_t)sample] = in[0];
+                p.wn[2 * (size_t)sample + 1] = in[1];
+            }
+            float *ew = ws.ew + (size_t)tile * kTile16, *dw = ws.dw + (size_t)tile * kTile32;
+            LevelFetch<float, 2, 2> f;
+#pragma unroll 1
+            for (int r = 0; r < 8; r++) {
+                float f0 = 0.0f, f1 = 0.0f, g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (on) {
+                    const LevelPlan &lp = plan_w[2 * r + h];
+                    issue_planned<float, 2, 2, false, false>(tw, lp, in, f);
+                    float res[2], grads[4];
+                    blend_level<float, 2, 2, true>(f, lp.scale, res, grads);
+                    f0 = res[0];
+                    f1 = res[1];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) g[q] = grads[q];
+                }
+                step32(a2, lds + F_S0, 16 + 2 * r, lane_off, f0);
+                step32(a2, lds + F_S0, 16 + 2 * r + 1, lane_off, f1);
+                ew[(2 * r) * 64 + lane] = f0;
+                ew[(2 * r + 1) * 64 + lane] = f1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) dw[(4 * r + q) * 64 + lane] = g[q];
+            }
+        }
+        // ---- sigma net: [enc_x | enc_w | eye] 65 -> 64 -> 64 -> 1 + 64
+        acc_relu(a2);
+        tile_store(ws.hs0 + (size_t)tile * kTile32, a2, lane);
+        acc_zero(a1);
+        layer_from_acc(a1, a2, lds + F_S1, lane_off);
+        acc_relu(a1);
+        tile_store(ws.hs1 + (size_t)tile * kTile32, a1, lane);
+        {
+            float raw[1];
+            valu_out<1>(a1, lds + F_S2R, h, raw);
+            if (h == 0) {
+                ws.sraw[sample] = raw[0];
+                if (live) p.sigmas[sample] = expf(raw[0]);   // trunc_exp forward (activation.py:9-11)
+            }
+        }
+        acc_zero(a0);
+        layer_from_acc(a0, a1, lds + F_S2, lane_off);   // geo_feat (no activation)
+        tile_store(ws.geo + (size_t)tile * kTile32, a0, lane);
+        // ---- color net: [SH(d) | geo_feat | ind_code] 84 -> 64 -> 3, sigmoid
+        acc_bias(a1, bias_col, h);
+        {
+            float sh[16];
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            if (live) {
+                dx = p.dirs[3 * (size_t)sample]; dy = p.dirs[3 * (size_t)sample + 1]; dz = p.dirs[3 * (size_t)sample + 2];
+            }
+            sh_basis<4>(dx, dy, dz, sh);
+            float *st = ws.sh + (size_t)tile * kTile8;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const uint32_t m = 0u - (uint32_t)h;   // lane half h supplies k = 2 s + h (bit-select: no dynamic indexing of sh[])
+                const float b = __uint_as_float((__float_as_uint(sh[2 * s]) & ~m) | (__float_as_uint(sh[2 * s + 1]) & m));
+                step32(a1, lds + F_C0, s, lane_off, b);
+                st[s * 64 + lane] = b;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; s++) step32(a1, lds + F_C0, 8 + s, lane_off, a0.v[s >> 4][s & 15]);
+        acc_relu(a1);
+        tile_store(ws.hc0 + (size_t)tile * kTile32, a1, lane);
+        {
+            float rgb[3];
+            valu_out<3>(a1, lds + F_C1, h, rgb);
+            if (live && h == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) p.rgbs[3 * (size_t)sample + c] = 1.0f / (1.0f + expf(-rgb[c]));
+            }
+        }
+    }
+}
+
+struct BwdParams {
+    const float *g_sigmas, *g_rgbs, *g_ambient, *g_ambient_abs;
+    const float *rgbs, *ambient;
+    uint32_t M;
+    const int32_t *m_dev;
+    const float *image;
+    float *ws;
+    float *g_enc_x, *g_enc_w;   // [16, M, 2]
+};
+
+__global__ void __launch_bounds__(kThreads) k_train_bwd(BwdParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kBwd];
+    const uint32_t M = live_count(p.M, p.m_dev);
+    const uint32_t n_tiles = (M + 31u) >> 5;
+    if (blockIdx.x * kWaves >= n_tiles) return;
+    for (int i = threadIdx.x; i < kBwd / 4; i += kThreads)
+        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(p.image + kFwd)[i];
+    __syncthreads();
+    const Ws ws = make_ws(p.ws, p.M);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int lane_off = h * 64 + j * 2;
+
+    for (uint32_t tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += gridDim.x * kWaves) {
+        const uint32_t sample = tile * 32 + j;
+        const bool live = sample < M;
+        Acc32 g, w;
+        // ---- colour net: sigmoid', last layer transposed, ReLU mask
+        {
+            float d[3] = {0.0f, 0.0f, 0.0f};
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float y = p.rgbs[3 * (size_t)sample + c];
+                    d[c] = p.g_rgbs[3 * (size_t)sample + c] * ((1.0f - y) * y);
+                }
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) ws.dprec[3 * (size_t)sample + c] = d[c];
+            }
+            acc_zero(g);
+            valu_out_T<3>(g, lds + N_C1, h, d);
+        }
+        relu_mask(g, ws.hc0 + (size_t)tile * kTile32, lane);
+        tile_store(ws.dzc0 + (size_t)tile * kTile32, g, lane);
+        acc_zero(w);
+        layer_from_acc(w, g, lds + T_C0, lane_off);       // d geo_feat
+        tile_store(ws.dgeo + (size_t)tile * kTile32, w, lane);
+        // ---- sigma net
+        {
+            float d[1] = {0.0f};
+            if (live) d[0] = p.g_sigmas[sample] * expf(fminf(fmaxf(ws.sraw[sample], -15.0f), 15.0f));   // activation.py:13-17
+            if (h == 0) ws.dsraw[sample] = d[0];
+            acc_zero(g);
+            layer_from_acc(g, w, lds + T_S2, lane_off);
+            valu_out_T<1>(g, lds + N_S2R, h, d);
+        }
+        relu_mask(g, ws.hs1 + (size_t)tile * kTile32, lane);
+        tile_store(ws.dzs1 + (size_t)tile * kTile32, g, lane);
+        acc_zero(w);
+        layer_from_acc(w, g, lds + T_S1, lane_off);
+        relu_mask(w, ws.hs0 + (size_t)tile * kTile32, lane);
+        tile_store(ws.dzs0 + (size_t)tile * kTile32, w, lane);
+        // d [enc_x | enc_w]: row tile 0 = enc_x, row tile 1 = enc_w, register 2 q + c of half h = (level 2 q + h, channel c)
+        f32x16 x0, x1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { x0[r] = 0.0f; x1[r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const float2 wv = *reinterpret_cast<const float2 *>(lds + T_S0 + s * kStep + lane_off);
+            const float b = w.v[s >> 4][s & 15];
+            x0 = mfma32(wv.x, b, x0);
+            x1 = mfma32(wv.y, b, x1);
+        }
+        // ---- ambient grid: feature gradients out (level-major), input gradient = sum_l g . dy_dx (gridencoder.cu:342-368);
+        // the encoder sees (ambient + 1) / 2 (gridencoder/grid.py:151, bound = 1): a factor 1/2 on the way back
+        float da[2] = {0.0f, 0.0f};
+        {
+            const float *dw = ws.dw + (size_t)tile * kTile32;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float g0 = x1[2 * q], g1 = x1[2 * q + 1];
+                const float d00 = dw[(4 * q + 0) * 64 + lane], d01 = dw[(4 * q + 1) * 64 + lane];
+                const float d10 = dw[(4 * q + 2) * 64 + lane], d11 = dw[(4 * q + 3) * 64 + lane];
+                da[0] = __builtin_fmaf(g0, d00, da[0]); da[0] = __builtin_fmaf(g1, d01, da[0]);
+                da[1] = __builtin_fmaf(g0, d10, da[1]); da[1] = __builtin_fmaf(g1, d11, da[1]);
+                if (live) *reinterpret_cast<float2 *>(p.g_enc_w + ((size_t)(2 * q + h) * p.M + sample) * 2) = make_float2(g0, g1);
+            }
+            da[0] += __shfl_xor(da[0], 32, 64);
+            da[1] += __shfl_xor(da[1], 32, 64);
+        }
+        // ---- ambient net: + the direct gradients of the ambient output, tanh'
+        {
+            float d[2] = {0.0f, 0.0f};
+            if (live) {
+                const float a0v = p.ambient[2 * (size_t)sample], a1v = p.ambient[2 * (size_t)sample + 1];
+                float t0 = 0.5f * da[0], t1 = 0.5f * da[1];
+                if (p.g_ambient) { t0 += p.g_ambient[2 * (size_t)sample]; t1 += p.g_ambient[2 * (size_t)sample + 1]; }
+                if (p.g_ambient_abs) {   // d |a| = sign(a), 0 at 0
+                    const float ga = p.g_ambient_abs[sample];
+                    t0 += a0v > 0.0f ? ga : (a0v < 0.0f ? -ga : 0.0f);
+                    t1 += a1v > 0.0f ? ga : (a1v < 0.0f ? -ga : 0.0f);
+                }
+                d[0] = t0 * (1.0f - a0v * a0v);
+                d[1] = t1 * (1.0f - a1v * a1v);
+            }
+            if (h == 0) { ws.daraw[2 * (size_t)sample] = d[0]; ws.daraw[2 * (size_t)sample + 1] = d[1]; }
+            acc_zero(g);
+            valu_out_T<2>(g, lds + N_A2, h, d);
+        }
+        relu_mask(g, ws.ha1 + (size_t)tile * kTile32, lane);
+        tile_store(ws.dza1 + (size_t)tile * kTile32, g, lane);
+        acc_zero(w);
+        layer_from_acc(w, g, lds + T_A1, lane_off);
+        relu_mask(w, ws.ha0 + (size_t)tile * kTile32, lane);
+        tile_store(ws.dza0 + (size_t)tile * kTile32, w, lane);
+#pragma unroll
+        for (int s = 0; s < 32; s++) x0 = mfma32(lds[T_A0 + s * 64 + h * 32 + j], w.v[s >> 4][s & 15], x0);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                *reinterpret_cast<float2 *>(p.g_enc_x + ((size_t)(2 * q + h) * p.M + sample) * 2) = make_float2(x0[2 * q], x0[2 * q + 1]);
+        }
+    }
+}
+
+// ---- weight gradients ---------------------------------------------------------------------------------------------------
+constexpr int kWThreads = 256;
+constexpr int kTS = 36;                  // LDS row stride of a staged tile: [feature][sample parity][sample / 2]
+constexpr int kStage = 96 * kTS;         // one operand tile: up to 96 features x 32 samples
+constexpr int PHI_STD = 0, PHI_ENC = 1, PHI_SH = 2;
+template <int PHI>
+__device__ __forceinline__ int phi(int q, int h) {   // feature of register q, lane half h of a native tile
+    if constexpr (PHI == PHI_STD) return 32 * (q >> 4) + rowmap(q & 15, h);
+    else if constexpr (PHI == PHI_ENC) return 4 * (q >> 1) + 2 * h + (q & 1);
+    else return 2 * q + h;
+}
+// An operand = [RM row-major columns | native segment 0 (R0 registers) | native segment 1 (R1 registers) | ones]
+template <int RM_, int R0_, int PHI0_, int R1_, int PHI1_, bool ONES_>
+struct OpT {
+    static constexpr int RM = RM_, R0 = R0_, PHI0 = PHI0_, R1 = R1_, PHI1 = PHI1_;
+    static constexpr bool ONES = ONES_;
+    static constexpr int NF = RM + 2 * R0 + 2 * R1 + (ONES ? 1 : 0);   // features
+    static constexpr int NB = (NF + 31) / 32;                          // 32-row blocks
+    static constexpr int S0 = R0 / 4, S1 = R1 / 4;                     // registers per thread (4 waves)
+};
+struct OpPtr {
+    const float *rm;   // [M_pad, RM]
+    const float *s0, *s1;
+};
+template <typename Op>
+struct Fetched {
+    float v0[Op::S0 > 0 ? Op::S0 : 1], v1[Op::S1 > 0 ? Op::S1 : 1], rm;
+};
+template <typename Op>
+__device__ __forceinline__ void fetch(Fetched<Op> &f, const OpPtr &o, uint32_t tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (Op::S0 > 0) {
+        const float *src = o.s0 + (size_t)tile * (Op::R0 * 64);
+#pragma unroll
+        for (int i = 0; i < Op::S0; i++) f.v0[i] = src[(wave * Op::S0 + i) * 64 + lane];
+    }
+    if constexpr (Op::S1 > 0) {
+        const float *src = o.s1 + (size_t)tile * (Op::R1 * 64);
+#pragma unroll
+        for (int i = 0; i < Op::S1; i++) f.v1[i] = src[(wave * Op::S1 + i) * 64 + lane];
+    }
+    if constexpr (Op::RM > 0) {
+        f.rm = 0.0f;
+        if (threadIdx.x < 32 * Op::RM) f.rm = o.rm[(size_t)tile * (32 * Op::RM) + threadIdx.x];
+    }
+}
+template <typename Op>
+__device__ __forceinline__ void commit(float *t, const Fetched<Op> &f, uint32_t tile, uint32_t M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int col = (j & 1) * 16 + (j >> 1);
+    if constexpr (Op::S0 > 0) {
+#pragma unroll
+        for (int i = 0; i < Op::S0; i++) t[(Op::RM + phi<Op::PHI0>(wave * Op::S0 + i, h)) * kTS + col] = f.v0[i];
+    }
+    if constexpr (Op::S1 > 0) {
+#pragma unroll
+        for (int i = 0; i < Op::S1; i++) t[(Op::RM + 2 * Op::R0 + phi<Op::PHI1>(wave * Op::S1 + i, h)) * kTS + col] = f.v1[i];
+    }
+    if constexpr (Op::RM > 0) {
+        if (threadIdx.x < 32 * Op::RM) {
+            const int s = threadIdx.x / Op::RM, c = threadIdx.x % Op::RM;
+            t[c * kTS + (s & 1) * 16 + (s >> 1)] = f.rm;
+        }
+    }
+    if constexpr (Op::ONES) {
+        if (threadIdx.x >= 64 && threadIdx.x < 96) {
+            const int s = threadIdx.x - 64;
+            t[(Op::NF - 1) * kTS + (s & 1) * 16 + (s >> 1)] = (tile * 32 + s < M) ? 1.0f : 0.0f;
+        }
+    }
+}
+
+// One workgroup = one job x one slice of the sample tiles; the NBa x NBb output blocks of 32 x 32 are dealt round-robin to
+// the 4 waves (<= 3 each), accumulators stay in registers over all tiles; tiles travel global -> registers two iterations
+// ahead of their use (the latency of a once-read tile is longer than its MFMA work).
+template <typename OpA, typename OpB>
+__device__ __forceinline__ void wgrad_job(const OpPtr &pa, const OpPtr &pb, uint32_t n_tiles, uint32_t M, uint32_t part, uint32_t parts,
+                                          float *__restrict__ partial, float *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    constexpr int NBLK = OpA::NB * OpB::NB;
+    static_assert(NBLK <= 12, "too many output blocks");
+    constexpr int NQ = (NBLK + 3) / 4;
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.0f;
+    float *ta = lds, *tb = lds + kStage;
+    for (int e = threadIdx.x; e < 2 * kStage; e += kWThreads) lds[e] = 0.0f;   // pad features stay zero
+    __syncthreads();
+    Fetched<OpA> fa0, fa1;
+    Fetched<OpB> fb0, fb1;
+    const uint32_t stride = parts;
+    if (part < n_tiles) { fetch<OpA>(fa0, pa, part); fetch<OpB>(fb0, pb, part); }
+    if (part + stride < n_tiles) { fetch<OpA>(fa1, pa, part + stride); fetch<OpB>(fb1, pb, part + stride); }
+    if (part < n_tiles) { commit<OpA>(ta, fa0, part, M); commit<OpB>(tb, fb0, part, M); }
+    __syncthreads();
+    auto multiply = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int b = wave + 4 * q;
+            if (b < NBLK) {
+                const int bx = b / OpB::NB, by = b - bx * OpB::NB;
+                const float4 *qa = reinterpret_cast<const float4 *>(ta + (32 * bx + i) * kTS + h * 16);
+                const float4 *qb = reinterpret_cast<const float4 *>(tb + (32 * by + i) * kTS + h * 16);
+                float4 av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { av[u] = qa[u]; bv[u] = qb[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc[q] = mfma32(av[u].x, bv[u].x, acc[q]);
+                    acc[q] = mfma32(av[u].y, bv[u].y, acc[q]);
+                    acc[q] = mfma32(av[u].z, bv[u].z, acc[q]);
+                    acc[q] = mfma32(av[u].w, bv[u].w, acc[q]);
+                }
+            }
+        }
+    };
+    for (uint32_t tile = part; tile < n_tiles; tile += 2 * stride) {
+        if (tile + 2 * stride < n_tiles) { fetch<OpA>(fa0, pa, tile + 2 * stride); fetch<OpB>(fb0, pb, tile + 2 * stride); }
+        multiply();
+        __syncthreads();
+        if (tile + stride < n_tiles) { commit<OpA>(ta, fa1, tile + stride, M); commit<OpB>(tb, fb1, tile + stride, M); }
+        __syncthreads();
+        if (tile + stride >= n_tiles) break;
+        if (tile + 3 * stride < n_tiles) { fetch<OpA>(fa1, pa, tile + 3 * stride); fetch<OpB>(fb1, pb, tile + 3 * stride); }
+        multiply();
+        __syncthreads();
+        if (tile + 2 * stride < n_tiles) { commit<OpA>(ta, fa0, tile + 2 * stride, M); commit<OpB>(tb, fb0, tile + 2 * stride, M); }
+        __syncthreads();
+    }
+    float *dst = partial + (size_t)part * (96 * 96);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int b = wave + 4 * q;
+        if (b < NBLK) {
+            const int bx = b / OpB::NB, by = b - bx * OpB::NB;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[(32 * bx + rowmap(r, h)) * 96 + 32 * by + i] = acc[q][r];
+        }
+    }
+}
+
+constexpr int kJobs = 8;
+enum { J_A0 = 0, J_A1, J_A2, J_S0, J_S1, J_S2, J_C0, J_C1 };
+typedef OpT<0, 32, PHI_STD, 0, 0, false> OpStd;                 // a 64-feature native tile
+typedef OpT<0, 16, PHI_ENC, 0, 0, true> OpEncX1;                // [enc_x | 1]
+typedef OpT<0, 16, PHI_ENC, 16, PHI_ENC, true> OpEncXW1;        // [enc_x | enc_w | 1]
+typedef OpT<0, 8, PHI_SH, 32, PHI_STD, true> OpShGeo1;          // [sh | geo_feat | 1]
+typedef OpT<2, 0, 0, 0, 0, false> OpRm2;
+typedef OpT<3, 0, 0, 0, 0, false> OpRm3;
+typedef OpT<1, 32, PHI_STD, 0, 0, false> OpRm1Std;              // [d sigma_raw | d geo_feat]
+
+struct WArgs {
+    float *ws;
+    uint32_t M;
+    const int32_t *m_dev;
+    uint32_t parts;
+    float *partial;     // [kJobs][parts][96 * 96]
+};
+
+__global__ void __launch_bounds__(kWThreads, 2) k_train_wgrad(WArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
+    const uint32_t job = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
+    const uint32_t M = live_count(p.M, p.m_dev), n_tiles = (M + 31u) >> 5;
+    const Ws w = make_ws(p.ws, p.M);
+    float *partial = p.partial + (size_t)job * p.parts * (96 * 96);
+    switch (job) {
+    case J_A0: wgrad_job<OpStd, OpEncX1>(OpPtr{nullptr, w.dza0, nullptr}, OpPtr{nullptr, w.ex, nullptr}, n_tiles, M, part, p.parts, partial, lds); break;
+    case J_A1: wgrad_job<OpStd, OpStd>(OpPtr{nullptr, w.dza1, nullptr}, OpPtr{nullptr, w.ha0, nullptr}, n_tiles, M, part, p.parts, partial, lds); break;
+    case J_A2: wgrad_job<OpRm2, OpStd>(OpPtr{w.daraw, nullptr, nullptr}, OpPtr{nullptr, w.ha1, nullptr}, n_tiles, M, part, p.parts, partial, lds); break;
+    case J_S0: wgrad_job<OpStd, OpEncXW1>(OpPtr{nullptr, w.dzs0, nullptr}, OpPtr{nullptr, w.ex, w.ew}, n_tiles, M, part, p.parts, partial, lds); break;
+    case J_S1: wgrad_job<OpStd, OpStd>(OpPtr{nullptr, w.dzs1, nullptr}, OpPtr{nullptr, w.hs0, nullptr}, n_tiles, M, part, p.parts, partial, lds); break;
+    case J_S2: wgrad_job<OpRm1Std, OpStd>(OpPtr{w.dsraw, w.dgeo, nullptr}, OpPtr{nullptr, w.hs1, nullptr}, n_tiles, M, part, p.parts, partial, lds); break;
+    case J_C0: wgrad_job<OpStd, OpShGeo1>(OpPtr{nullptr, w.dzc0, nullptr}, OpPtr{nullptr, w.sh, w.geo}, n_tiles, M, part, p.parts, partial, lds); break;
+    default: wgrad_job<OpRm3, OpStd>(OpPtr{w.dprec, nullptr, nullptr}, OpPtr{nullptr, w.hc0, nullptr}, n_tiles, M, part, p.parts, partial, lds); break;
+    }
+}
+
+struct RJob {
+    float *out;
+    uint32_t rows, cols, ld;      // out[row * ld + col] for row < rows, col < cols
+    int32_t bias_col;             // column of the partial that is the bias gradient (-1: none)
+    float *bias_out;              // [rows]
+};
+struct RArgs {
+    RJob job[kJobs];
+    const float *partial;
+    uint32_t parts;
+};
+__global__ void __launch_bounds__(256) k_train_wreduce(RArgs p) {
+    const RJob &job = p.job[blockIdx.y];
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t row = e / 96, col = e % 96;
+    const bool bias = job.bias_col >= 0 && (int32_t)col == job.bias_col;
+    if (row >= job.rows || (col >= job.cols && !bias)) return;
+    const float *src = p.partial + (size_t)blockIdx.y * p.parts * (96 * 96) + row * 96 + col;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t q = 0;
+    for (; q + 8 <= p.parts; q += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) s[u] += src[(size_t)(q + u) * (96 * 96)];
+    }
+    for (; q < p.parts; q++) s[0] += src[(size_t)q * (96 * 96)];
+    const float total = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (bias) job.bias_out[row] = total;
+    else job.out[row * job.ld + col] = total;
+}
+
+// The per-call constants enter the first layers as biases (k_train_pack).  With gb = the bias gradient [64]:
+//   d constant[a] = sum_u W0[u][c0 + a] gb[u]        d W0[u][c0 + a] = gb[u] constant[a]
+struct CArgs {
+    RawW w;
+    const float *enc_a, *eye, *ind_code;
+    const float *gb;    // [3][64]
+    float *g_a0, *g_s0, *g_c0, *g_enc_a, *g_eye, *g_ind;
+};
+__global__ void __launch_bounds__(256) k_train_const(CArgs p) {
+    const int which = blockIdx.x;
+    const float *W, *c, *gb = p.gb + 64 * which;
+    float *gW, *gc;
+    uint32_t n, ld, c0;
+    if (which == 0) { W = p.w.amb_w0; c = p.enc_a; gW = p.g_a0; gc = p.g_enc_a; n = p.w.audio_dim; c0 = 32; }
+    else if (which == 1) { W = p.w.sig_w0; c = p.eye; gW = p.g_s0; gc = p.g_eye; n = p.w.has_eye; c0 = 64; }
+    else { W = p.w.col_w0; c = p.ind_code; gW = p.g_c0; gc = p.g_ind; n = p.w.ind_dim; c0 = 80; }
+    ld = c0 + n;
+    for (uint32_t e = threadIdx.x; e < 64 * n; e += 256) {
+        const uint32_t u = e / n, a = e - u * n;
+        gW[u * ld + c0 + a] = gb[u] * c[a];
+    }
+    for (uint32_t a = threadIdx.x; a < n; a += 256) {
+        float s = 0.0f;
+        for (uint32_t u = 0; u < 64; u++) s += W[u * ld + c0 + a] * gb[u];
+        if (gc) gc[a] = s;
+    }
+}
+
+// ---- table gradient -------------------------------------------------------------------------------------------------------
+constexpr uint32_t kScThreads = 256, kScSamples = 128, kScSlots = 1024, kScProbes = 24;
+constexpr uint32_t kScEmpty = 0xffffffffu;
+
+// Lanes hold (key, v[4]); consecutive lanes with equal keys form a run (ray-ordered samples stay in one coarse cell for many
+// steps).  A segmented inclusive scan sums each run into its last lane, which alone goes on to the LDS table.
+__device__ __forceinline__ bool merge_runs4(uint32_t key, uint32_t key2, float (&v)[4]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64), prev2 = (uint32_t)__shfl_up((int)key2, 1, 64);
+    const bool head = lane == 0 || key != prev || key2 != prev2;   // a run = both destination rows equal
+    const unsigned long long heads = __ballot(head);
+    if (__popcll(heads) > 40) return key != kScEmpty;
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    const uint32_t start = 63u - (uint32_t)__clzll(below);
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        float up[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) up[c] = __shfl_up(v[c], off, 64);
+        if (lane >= start + off) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] += up[c];
+        }
+    }
+    const bool tail = lane == 63u || ((heads >> (lane + 1)) & 1ull);
+    return tail && key != kScEmpty;
+}
+
+template <uint32_t D>
+__global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                             const int32_t *__restrict__ offsets, float *__restrict__ grad_grid,
+                                                             uint32_t Mcap, const int32_t *__restrict__ m_dev, LevelConsts lc,
+                                                             uint32_t gridtype) {
+    constexpr uint32_t P = 1u << (D - 1);            // x-pairs of corners per sample
+    constexpr uint32_t PT = P / 2;                   // pairs per thread: the 128 samples take lanes 0..127 and 128..255
+    __shared__ uint32_t keys[kScSlots];
+    __shared__ __attribute__((aligned(16))) float vals[kScSlots * 16];
+    const uint32_t M = live_count(Mcap, m_dev);
+    if (blockIdx.x * kScSamples >= M) return;
+    for (uint32_t i = threadIdx.x; i < kScSlots; i += kScThreads) keys[i] = kScEmpty;
+    for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) vals[i] = 0.0f;
+    __syncthreads();
+    const uint32_t level = blockIdx.y;
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    float *gg = grad_grid + (size_t)off * 2;
+    const uint32_t b = blockIdx.x * kScSamples + (threadIdx.x & (kScSamples - 1u));
+    const uint32_t pset = threadIdx.x / kScSamples;   // which half of the x-pairs
+    float in[D];
+    bool live = b < M;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = live ? inputs[(size_t)b * D + d] : 0.0f;
+        live = live && !(in[d] < 0 || in[d] > 1);     // gridencoder.cu:275-280
+    }
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+    lattice_pos<D>(in, lc.scale[level], false, 0, pos, pos_deriv, pos_grid);
+    float2 g = make_float2(0.0f, 0.0f);
+    if (live) g = *reinterpret_cast<const float2 *>(grad + ((size_t)level * Mcap + b) * 2);
+    const uint32_t resolution = lc.resolution[level];
+#pragma unroll
+    for (uint32_t t = 0; t < PT; t++) {
+        const uint32_t q = pset * PT + t;             // bits of q: the y (, z) corner
+        uint32_t pgl[D];
+        pgl[0] = pos_grid[0];
+        float wyz[2] = {1.0f - pos[0], pos[0]};       // the reference multiplies the x term first (gridencoder.cu:298-308)
+#pragma unroll
+        for (uint32_t d = 1; d < D; d++) {
+            const bool hi = (q >> (d - 1)) & 1u;
+            const float wd = hi ? pos[d] : 1 - pos[d];
+            wyz[0] *= wd;
+            wyz[1] *= wd;
+            pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
+        }
+        uint32_t row0 = kScEmpty, row1 = kScEmpty;
+        if (live) {
+            row0 = grid_row<D>(gridtype, false, hashmap_size, resolution, pgl);
+            pgl[0] += 1u;
+            row1 = grid_row<D>(gridtype, false, hashmap_size, resolution, pgl);
+        }
+        float v[4] = {wyz[0] * g.x, wyz[0] * g.y, wyz[1] * g.x, wyz[1] * g.y};
+        if (merge_runs4(row0, row1, v)) {
+            const uint32_t rows[2] = {row0, row1};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const uint32_t line = rows[e] >> 3, sub = rows[e] & 7u;
+                uint32_t slot = (line * 2654435761u) >> 22;   // 10 bits
+                bool placed = false;
+                for (uint32_t probe = 0; probe < kScProbes; probe++) {
+                    const uint32_t prev = atomicCAS(&keys[slot], kScEmpty, line);
+                    if (prev == kScEmpty || prev == line) { placed = true; break; }
+                    slot = (slot + 1u) & (kScSlots - 1u);
+                }
+                if (placed) {
+                    atomicAdd(&vals[slot * 16 + sub * 2], v[2 * e]);
+                    atomicAdd(&vals[slot * 16 + sub * 2 + 1], v[2 * e + 1]);
+                } else {   // table full around this line (never with 2-D grids): straight to memory
+                    atomicAdd(gg + (size_t)rows[e] * 2, v[2 * e]);
+                    atomicAdd(gg + (size_t)rows[e] * 2 + 1, v[2 * e + 1]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 16 adjacent lanes = the 16 floats of one 64-B line of the gradient table: one memory-side request per touched line
+    for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) {
+        const uint32_t line = keys[i >> 4];
+        if (line != kScEmpty) {
+            const float v = vals[i];
+            if (v != 0.0f) atomicAdd(gg + (size_t)line * 16 + (i & 15u), v);
+        }
+    }
+}
+
+// ---- loss on the composited rays -----------------------------------------------------------------------------------------
+constexpr int kLossThreads = 1024;
+__global__ void __launch_bounds__(kLossThreads) k_train_head_loss(const float *__restrict__ image, const float *__restrict__ ws,
+                                                                  const float *__restrict__ ambient, const float *__restrict__ bg,
+                                                                  uint32_t bg_stride, const float *__restrict__ target, uint32_t target_stride,
+                                                                  const float *__restrict__ face, uint32_t face_stride,
+                                                                  const float *__restrict__ w_amb, uint32_t N, float *__restrict__ loss,
+                                                                  float *__restrict__ pred, float *__restrict__ g_image,
+                                                                  float *__restrict__ g_ws, float *__restrict__ g_amb) {
+    __shared__ double red[kLossThreads / kWave];
+    const float wa = w_amb[0];
+    const float inv_n = 1.0f / (float)N;
+    double acc = 0.0;
+    for (uint32_t n = threadIdx.x; n < N; n += kLossThreads) {
+        const float w = ws[n];
+        const float tr = 1.0f - w;                     // nerf/renderer.py:306: image + (1 - weights_sum) * bg, clamp [0, 1]
+        float mse = 0.0f, gws_blend = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float b = bg[(size_t)n * bg_stride + c];
+            const float raw = image[n * 3 + c] + tr * b;
+            const float pr = fminf(fmaxf(raw, 0.0f), 1.0f);
+            if (pred) pred[n * 3 + c] = pr;
+            const float d = pr - target[(size_t)n * target_stride + c];
+            mse += d * d;
+            const float gp = (raw >= 0.0f && raw <= 1.0f) ? 2.0f * d * (inv_n / 3.0f) : 0.0f;   // clamp passes the gradient on [0, 1]
+            g_image[n * 3 + c] = gp;
+            gws_blend -= gp * b;
+        }
+        const float a = fminf(fmaxf(w, 1e-5f), 1.0f - 1e-5f);
+        const float la = log2f(a), lb = log2f(1.0f - a);
+        const float ent = -a * la - (1.0f - a) * lb;
+        const bool inside = w >= 1e-5f && w <= 1.0f - 1e-5f;
+        g_ws[n] = gws_blend + (inside ? 1e-4f * inv_n * (lb - la) : 0.0f);
+        const float keep = 1.0f - face[(size_t)n * face_stride];
+        g_amb[n] = wa * inv_n * keep;
+        acc += (double)(mse / 3.0f) * inv_n + 1e-4 * (double)ent * inv_n + (double)wa * (double)(ambient[n] * keep) * inv_n;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kLossThreads / kWave; w++) t += red[w];
+        loss[0] = (float)t;
+    }
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+constexpr uint32_t kWPartsMax = 256;
+static uint32_t wparts() {   // workgroups (= partial sums) per weight-gradient job
+    static uint32_t n = 0;
+    if (!n) {
+        const char *e = getenv("RN_TRAIN_WPARTS");
+        const long v = e ? atol(e) : 96;
+        n = (uint32_t)(v < 1 ? 1 : (v > (long)kWPartsMax ? (long)kWPartsMax : v));
+    }
+    return n;
+}
+static RawW raw_w(const rn_nerf_weights_t *w) {
+    return RawW{w->amb_w0, w->amb_w1, w->amb_w2, w->sig_w0, w->sig_w1, w->sig_w2, w->col_w0, w->col_w1, w->audio_dim, w->has_eye, w->ind_dim};
+}
+static int check_w(const rn_nerf_weights_t *w) {
+    RN_REQUIRE(w && w->amb_w0 && w->amb_w1 && w->amb_w2 && w->sig_w0 && w->sig_w1 && w->sig_w2 && w->col_w0 && w->col_w1,
+               "train_head: null weight pointer");
+    RN_REQUIRE(w->has_eye <= 1, "train_head: has_eye must be 0 or 1");
+    return RN_OK;
+}
+static int check_grid(const rn_grid_t *g, uint32_t D, const char *name) {
+    RN_REQUIRE(g && g->embeddings && g->offsets, "train_head: %s grid is null", name);
+    RN_REQUIRE(g->D == D && g->L == 16 && g->dtype == RN_F32, "train_head: %s grid must be D=%u, L=16, fp32 with C=2", name, D);
+    return RN_OK;
+}
+static GridArgs grid_args(const rn_grid_t *g) {
+    return GridArgs{g->embeddings, g->offsets, make_level_consts(g->L, g->S, g->H), g->gridtype};
+}
+
+}  // namespace th
+}  // namespace rn
+
+using namespace rn;
+using namespace rn::th;
+
+extern "C" {
+
+size_t rn_train_head_image_floats(void) { return (size_t)kImage; }
+size_t rn_train_head_workspace_floats(uint32_t M) { return (size_t)((M + 31u) >> 5) * kWsPerTile; }
+size_t rn_train_head_wgrad_workspace(void) { return ((size_t)kJobs * kWPartsMax * 96 * 96 + 192) * sizeof(float); }
+
+int rn_train_head_pack(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code, float *image,
+                       rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(image && ((uintptr_t)image & 15u) == 0, "train_head_pack: image must be 16-byte aligned");
+    RN_REQUIRE((enc_a || w->audio_dim == 0) && (eye || !w->has_eye) && (ind_code || w->ind_dim == 0), "train_head_pack: null constant");
+    hipLaunchKernelGGL(k_train_pack, dim3(div_up(kImage, 256)), dim3(256), 0, as_stream(stream), raw_w(w), enc_a, eye, ind_code, image);
+    return check_launch("train_head_pack");
+}
+
+int rn_train_head_forward(const float *xyzs, const float *dirs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid_xyz,
+                          const rn_grid_t *grid_amb, const float *image, float bound, float *sigmas, float *rgbs,
+                          float *ambient, float *ambient_abs, float *xn, float *wn, float *workspace, rn_stream_t stream) {
+    if (M == 0) return RN_OK;
+    if (int rc = check_grid(grid_xyz, 3, "xyz")) return rc;
+    if (int rc = check_grid(grid_amb, 2, "ambient")) return rc;
+    RN_REQUIRE(xyzs && dirs && image && sigmas && rgbs && ambient && xn && wn && workspace, "train_head_forward: null pointer");
+    RN_REQUIRE(((uintptr_t)image & 15u) == 0 && ((uintptr_t)workspace & 15u) == 0, "train_head_forward: image / workspace must be 16-byte aligned");
+    FwdParams p{xyzs, dirs, M, m_dev, grid_args(grid_xyz), grid_args(grid_amb), image, bound, sigmas, rgbs, ambient, ambient_abs, xn, wn, workspace};
+    const uint32_t n_tiles = (M + 31u) >> 5;
+    uint32_t blocks = div_up(n_tiles, kWaves);
+    const uint32_t cap = (uint32_t)num_cus();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_train_fwd, dim3(blocks), dim3(kThreads), 0, as_stream(stream), p);
+    return check_launch("train_head_forward");
+}
+
+int rn_train_head_backward(const float *grad_sigmas, const float *grad_rgbs, const float *grad_ambient,
+                           const float *grad_ambient_abs, const float *rgbs, const float *ambient, uint32_t M,
+                           const int32_t *m_dev, const float *image, float *workspace, float *grad_enc_x, float *grad_enc_w,
+                           rn_stream_t stream) {
+    if (M == 0) return RN_OK;
+    RN_REQUIRE(grad_sigmas && grad_rgbs && rgbs && ambient && image && workspace && grad_enc_x && grad_enc_w, "train_head_backward: null pointer");
+    RN_REQUIRE(((uintptr_t)grad_enc_x & 7u) == 0 && ((uintptr_t)grad_enc_w & 7u) == 0, "train_head_backward: feature gradients must be 8-byte aligned");
+    BwdParams p{grad_sigmas, grad_rgbs, grad_ambient, grad_ambient_abs, rgbs, ambient, M, m_dev, image, workspace, grad_enc_x, grad_enc_w};
+    const uint32_t n_tiles = (M + 31u) >> 5;
+    uint32_t blocks = div_up(n_tiles, kWaves);
+    const uint32_t cap = (uint32_t)num_cus();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_train_bwd, dim3(blocks), dim3(kThreads), 0, as_stream(stream), p);
+    return check_launch("train_head_backward");
+}
+
+int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
+                               uint32_t M, const int32_t *m_dev, const float *workspace, const rn_train_head_grads_t *g,
+                               void *wgrad_workspace, rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(M > 0 && workspace && g && wgrad_workspace, "train_head_weight_grads: null pointer / M == 0");
+    RN_REQUIRE(g->amb_w0 && g->amb_w1 && g->amb_w2 && g->sig_w0 && g->sig_w1 && g->sig_w2 && g->col_w0 && g->col_w1,
+               "train_head_weight_grads: null gradient pointer");
+    RN_REQUIRE((enc_a || w->audio_dim == 0) && (eye || !w->has_eye) && (ind_code || w->ind_dim == 0), "train_head_weight_grads: null constant");
+    hipStream_t s = as_stream(stream);
+    float *partial = static_cast<float *>(wgrad_workspace);
+    float *gb = partial + (size_t)kJobs * kWPartsMax * 96 * 96;
+    WArgs a{const_cast<float *>(workspace), M, m_dev, wparts(), partial};
+    hipLaunchKernelGGL(k_train_wgrad, dim3(kJobs * a.parts), dim3(kWThreads), 0, s, a);
+    const uint32_t ldA0 = 32 + w->audio_dim, ldS0 = 64 + w->has_eye, ldC0 = 80 + w->ind_dim;
+    RArgs r{};
+    r.partial = partial;
+    r.parts = a.parts;
+    r.job[J_A0] = RJob{g->amb_w0, 64, 32, ldA0, 32, gb};
+    r.job[J_A1] = RJob{g->amb_w1, 64, 64, 64, -1, nullptr};
+    r.job[J_A2] = RJob{g->amb_w2, 2, 64, 64, -1, nullptr};
+    r.job[J_S0] = RJob{g->sig_w0, 64, 64, ldS0, 64, gb + 64};
+    r.job[J_S1] = RJob{g->sig_w1, 64, 64, 64, -1, nullptr};
+    r.job[J_S2] = RJob{g->sig_w2, 65, 64, 64, -1, nullptr};
+    r.job[J_C0] = RJob{g->col_w0, 64, 80, ldC0, 80, gb + 128};
+    r.job[J_C1] = RJob{g->col_w1, 3, 64, 64, -1, nullptr};
+    hipLaunchKernelGGL(k_train_wreduce, dim3(div_up(96 * 96, 256), kJobs), dim3(256), 0, s, r);
+    CArgs c{raw_w(w), enc_a, eye, ind_code, gb, g->amb_w0, g->sig_w0, g->col_w0, g->enc_a, g->eye, g->ind_code};
+    hipLaunchKernelGGL(k_train_const, dim3(3), dim3(256), 0, s, c);
+    return check_launch("train_head_weight_grads");
+}
+
+int rn_grid_scatter_lbc(const float *grad, const float *inputs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid,
+                        float *grad_table, rn_stream_t stream) {
+    if (M == 0) return RN_OK;
+    RN_REQUIRE(grad && inputs && grid && grid->embeddings == grid->embeddings && grid->offsets && grad_table, "grid_scatter_lbc: null pointer");
+    RN_REQUIRE((grid->D == 2 || grid->D == 3) && grid->L >= 1 && grid->L <= kMaxLevels, "grid_scatter_lbc: D must be 2 or 3, L <= 32");
+    RN_REQUIRE(((uintptr_t)grad_table & 63u) == 0 && ((uintptr_t)grad & 7u) == 0, "grid_scatter_lbc: grad_table must be 64-byte, grad 8-byte aligned");
+    const LevelConsts lc = make_level_consts(grid->L, grid->S, grid->H);
+    const dim3 g(div_up(M, kScSamples), grid->L);
+    if (grid->D == 3)
+        hipLaunchKernelGGL(k_grid_scatter<3>, g, dim3(kScThreads), 0, as_stream(stream), grad, inputs, grid->offsets, grad_table, M, m_dev, lc, grid->gridtype);
+    else
+        hipLaunchKernelGGL(k_grid_scatter<2>, g, dim3(kScThreads), 0, as_stream(stream), grad, inputs, grid->offsets, grad_table, M, m_dev, lc, grid->gridtype);
+    return check_launch("grid_scatter_lbc");
+}
+
+int rn_train_head_loss(const float *image, const float *weights_sum, const float *ambient, const float *bg, uint32_t bg_stride,
+                       const float *target, uint32_t target_stride, const float *face, uint32_t face_stride, const float *w_amb,
+                       uint32_t N, float *loss, float *pred, float *grad_image, float *grad_weights_sum, float *grad_ambient,
+                       rn_stream_t stream) {
+    RN_REQUIRE(N > 0, "train_head_loss: N must be positive");
+    RN_REQUIRE(image && weights_sum && ambient && bg && target && face && w_amb && loss && grad_image && grad_weights_sum && grad_ambient,
+               "train_head_loss: null pointer");
+    hipLaunchKernelGGL(k_train_head_loss, dim3(1), dim3(kLossThreads), 0, as_stream(stream), image, weights_sum, ambient, bg, bg_stride, target,
+                       target_stride, face, face_stride, w_amb, N, loss, pred, grad_image, grad_weights_sum, grad_ambient);
+    return check_launch("train_head_loss");
+}
+
+}  // extern "C"

@@ -91,6 +91,18 @@ class _SkinnyLinear(torch.autograd.Function):
 _MLP_KERNELS = []
 _AUDIO_KERNELS = []
 _TRAIN_GLUE = []
+_TRAIN_HEAD = []
+
+
+def _train_head():
+    """radnerf.train_head (the whole per-sample network as one forward + one backward kernel; needs the HIP library and a GPU),
+    or None on the CPU."""
+    if not torch.cuda.is_available():
+        return None
+    if not _TRAIN_HEAD:
+        from . import train_head
+        _TRAIN_HEAD.append(train_head)
+    return _TRAIN_HEAD[0]
 
 
 def _train_glue():
@@ -264,6 +276,12 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d, enc_a, c, e=None):
         # nerf/network.py:222-283; x: [N,3] in [-bound,bound], d: [N,3], enc_a: [1,64], c: [ind_dim], e: [1,1]
+        th = _train_head()
+        if th is not None and th.usable(self, x, enc_a):
+            # training on the GPU: the whole network as one forward and one backward kernel (radnerf/train_head.py);
+            # RN_TRAIN_HEAD=ops keeps the per-operator path below (the parity tests compare the two)
+            sigma, color, ambient, _ = th.head_forward(self, x, d, enc_a, c, e)
+            return sigma, color, ambient
         h, ambient = self._geometry(x, enc_a, e)
         enc_d = self.encoder_dir(d)
         glue = _train_glue()

@@ -190,13 +190,18 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
-        sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
-        from .network import _train_glue
-        glue = _train_glue()
-        if glue is not None and ambient.dim() == 2 and ambient.shape[1] == 2 and glue.enabled(ambient):
-            ambient_abs = glue.abs_sum2(ambient)
+        from .network import _train_glue, _train_head
+        th = _train_head()
+        if th is not None and th.usable(self, xyzs, enc_a):
+            # one forward kernel for the network (+ |ambient| sum); the marcher's counter bounds the rows it visits
+            sigmas, rgbs, ambient, ambient_abs = th.head_forward(self, xyzs, dirs, enc_a, ind_code, eye, m_dev=counter)
         else:
-            ambient_abs = ambient.abs().sum(-1)
+            sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
+            glue = _train_glue()
+            if glue is not None and ambient.dim() == 2 and ambient.shape[1] == 2 and glue.enabled(ambient):
+                ambient_abs = glue.abs_sum2(ambient)
+            else:
+                ambient_abs = ambient.abs().sum(-1)
         if self.density_scale != 1:
             sigmas = self.density_scale * sigmas
         weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient_abs, deltas, rays)
@@ -283,6 +288,10 @@ class NeRFRenderer(nn.Module):
             head = self._head_inference_ops(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps, T_thresh)
 
         background = 1 if bg_color is None else bg_color
+        if self.training and kwargs.get("defer_blend") and not self.torso and torch.is_tensor(background):
+            # the caller blends, clamps and takes the loss in one kernel (radnerf/train.py: train_head.head_loss)
+            results["head_image"], results["background"] = head["image"], background
+            return results
         if self.torso:
             background = self._torso_layer(bg_coords, poses, enc_a, index, background, results)
         elif torch.is_tensor(background):

@@ -163,9 +163,20 @@ def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1, am
     eye [B,1], auds, index, bg_color [B,N,3], images (head) or bg_torso_color (torso) [B,N,3]."""
     torso = bool(opt.torso)
     rgb = data["bg_torso_color"] if torso else data["images"]
+    import os
+    fused_loss = (not torso and rgb.is_cuda and rgb.dtype == torch.float32 and os.environ.get("RN_TRAIN_LOSS", "fused") == "fused"
+                  and torch.is_tensor(data.get("bg_color")) and data["bg_color"].dtype == torch.float32)
     out = model.render(data["rays_o"], data["rays_d"], data["auds"], data["bg_coords"], data["poses"], eye=data["eye"],
                        index=data["index"], staged=False, bg_color=data["bg_color"], perturb=True, force_all_rays=False,
-                       dt_gamma=opt.dt_gamma, max_steps=opt.max_steps)
+                       dt_gamma=opt.dt_gamma, max_steps=opt.max_steps, defer_blend=fused_loss)
+    if "head_image" in out:
+        # blend over the background (nerf/renderer.py:306), clamp and the loss below with their gradients: ONE kernel
+        from . import train_head
+        face = data["face_mask"]
+        face = face if face.dtype == torch.float32 else face.float()
+        w = amb_weight if amb_weight is not None else torch.full((1,), min(global_step / iters, 1.0) * lambda_amb, device=rgb.device)
+        loss, pred = train_head.head_loss(out["head_image"], out["weights_sum"], out["ambient"], out["background"], rgb, face, w)
+        return pred.view(rgb.shape), rgb, loss
     pred = out["torso_color"] if torso else out["image"]
     if not torso and pred.is_cuda:
         from . import train_glue

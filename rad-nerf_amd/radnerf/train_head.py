@@ -1,0 +1,220 @@
+"""NeRFNetwork.forward under autograd as one forward and one backward kernel (csrc/rn_train_head.hip, C ABI
+include/radnerf_train.h).
+
+Reference: NeRFNetwork.forward (nerf/network.py:222-283) in the train branch of NeRFRenderer.run_cuda
+(nerf/renderer.py:206-223), differentiated by torch.autograd in Trainer.train_step (nerf/utils.py:718-806).  One call of
+`head_forward` is 2 launches (weight images + the network), its backward 6 (network, weight gradients + reduction + constant
+columns, one table scatter per grid) plus the two memsets of the table gradients -- against ~130 launches of grid / MLP /
+activation / concatenation kernels.  Differentiable in both grid tables, the eight weight matrices, the audio code, the eye
+value and the individual code; the sample positions and directions receive no gradient (as in the reference: the grid inputs
+do not require grad unless --train_camera, which keeps the per-operator path).
+"""
+import ctypes as C
+
+import torch
+
+import radnerf_hip as hip
+
+from .fused import GridT, NerfWeightsT, _grid_desc
+
+_lib = hip._lib
+_ptr, _u32, _f32 = C.c_void_p, C.c_uint32, C.c_float
+
+
+class HeadGradsT(C.Structure):
+    _fields_ = [(n, _ptr) for n in ("amb_w0", "amb_w1", "amb_w2", "sig_w0", "sig_w1", "sig_w2", "col_w0", "col_w1", "enc_a", "eye", "ind_code")]
+
+
+_SIGS = {
+    "rn_train_head_pack": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_train_head_forward": [_ptr, _ptr, _u32, _ptr, C.POINTER(GridT), C.POINTER(GridT), _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                              _ptr, _ptr],
+    "rn_train_head_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_train_head_weight_grads": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _u32, _ptr, _ptr, C.POINTER(HeadGradsT), _ptr, _ptr],
+    "rn_grid_scatter_lbc": [_ptr, _ptr, _u32, _ptr, C.POINTER(GridT), _ptr, _ptr],
+    "rn_train_head_loss": [_ptr, _ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _u32, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+}
+for _n, _a in _SIGS.items():
+    getattr(_lib, _n).argtypes = _a
+    getattr(_lib, _n).restype = C.c_int
+for _n in ("rn_train_head_image_floats", "rn_train_head_workspace_floats", "rn_train_head_wgrad_workspace"):
+    getattr(_lib, _n).restype = C.c_size_t
+_lib.rn_train_head_workspace_floats.argtypes = [_u32]
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + ["rn_train_head_image_floats", "rn_train_head_workspace_floats", "rn_train_head_wgrad_workspace"])
+
+
+def supported(model):
+    """The network shape the kernels are built for (= the fused inference engine's), fp32 tables, no --emb / --train_camera."""
+    from . import fused
+    return (fused.supported(model) and model.encoder.embeddings.dtype == torch.float32 and model.encoder_ambient.embeddings.dtype == torch.float32
+            and model.audio_dim > 0 and not model.train_camera)
+
+
+def _weights_of(model):
+    return [l.weight for l in model.ambient_net.net] + [l.weight for l in model.sigma_net.net] + [l.weight for l in model.color_net.net]
+
+
+def _weights_desc(ws, audio_dim, has_eye, ind_dim):
+    nw = NerfWeightsT()
+    (nw.amb_w0, nw.amb_w1, nw.amb_w2, nw.sig_w0, nw.sig_w1, nw.sig_w2, nw.col_w0, nw.col_w1) = [w.data_ptr() for w in ws]
+    nw.audio_dim, nw.has_eye, nw.ind_dim = audio_dim, has_eye, ind_dim
+    return nw
+
+
+class _HeadTrain(torch.autograd.Function):
+    """(sigma [M], rgb [M,3], ambient [M,2], |ambient|.sum(-1) [M]) = NeRFNetwork.forward(xyzs, dirs, enc_a, ind_code, eye)."""
+
+    @staticmethod
+    def forward(ctx, xyzs, dirs, enc_a, eye, ind_code, m_dev, meta, table_x, table_w, *ws):
+        enc_x, enc_w, bound = meta
+        dev = xyzs.device
+        M = xyzs.shape[0]
+        xyzs, dirs = xyzs.contiguous(), dirs.contiguous()
+        ws = [w.contiguous() for w in ws]
+        audio_dim, has_eye, ind_dim = ws[0].shape[1] - 32, ws[3].shape[1] - 64, ws[6].shape[1] - 80
+        enc_a_c = enc_a.reshape(-1).contiguous().float()
+        eye_c = eye.reshape(-1).contiguous().float() if has_eye else None
+        ind_c = ind_code.reshape(-1).contiguous().float() if ind_dim else None
+        tx, tw = hip.aligned(table_x.detach(), 64), hip.aligned(table_w.detach(), 64)
+        nw = _weights_desc(ws, audio_dim, has_eye, ind_dim)
+        gx, gw = _grid_desc(enc_x, tx), _grid_desc(enc_w, tw)
+        s = hip.stream()
+        image = torch.empty(int(_lib.rn_train_head_image_floats()), dtype=torch.float32, device=dev)
+        hip.call("rn_train_head_pack", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), hip.ptr(image), s)
+        work = torch.empty(int(_lib.rn_train_head_workspace_floats(M)), dtype=torch.float32, device=dev)
+        # one block for the outputs: rows past the live count are never written by the kernel and must read as zero
+        out = torch.zeros(M, 12, dtype=torch.float32, device=dev) if m_dev is not None else torch.empty(M, 12, dtype=torch.float32, device=dev)
+        flat = out.view(-1)
+        sigmas, amb_abs = flat[0:M], flat[M:2 * M]
+        rgbs, ambient = flat[2 * M:5 * M].view(M, 3), flat[5 * M:7 * M].view(M, 2)
+        xn, wn = flat[7 * M:10 * M].view(M, 3), flat[10 * M:12 * M].view(M, 2)
+        if M:
+            hip.call("rn_train_head_forward", hip.ptr(xyzs), hip.ptr(dirs), M, hip.ptr(m_dev), C.byref(gx), C.byref(gw), hip.ptr(image),
+                     float(bound), sigmas.data_ptr(), rgbs.data_ptr(), ambient.data_ptr(), amb_abs.data_ptr(), xn.data_ptr(), wn.data_ptr(),
+                     hip.ptr(work), s)
+        ctx.save_for_backward(image, work, out, m_dev, tx, tw, enc_a_c, eye_c, ind_c, *ws)
+        ctx.meta = (enc_x, enc_w, M, audio_dim, has_eye, ind_dim, enc_a.shape, None if eye is None else eye.shape,
+                    None if ind_code is None else ind_code.shape, table_x.dtype)
+        return sigmas, rgbs, ambient, amb_abs
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb, g_ambient, g_amb_abs):
+        image, work, out, m_dev, tx, tw, enc_a_c, eye_c, ind_c, *ws = ctx.saved_tensors
+        enc_x, enc_w, M, audio_dim, has_eye, ind_dim, enc_a_shape, eye_shape, ind_shape, _ = ctx.meta
+        dev = image.device
+        s = hip.stream()
+        flat = out.view(-1)
+        rgbs, ambient = flat[2 * M:5 * M], flat[5 * M:7 * M]
+        xn, wn = flat[7 * M:10 * M], flat[10 * M:12 * M]
+
+        def dense(g, shape):
+            if g is None:
+                return None
+            g = g.contiguous()
+            return g if g.dtype == torch.float32 else g.float()
+        g_sigma = dense(g_sigma, (M,))
+        g_rgb = dense(g_rgb, (M, 3))
+        if g_sigma is None:
+            g_sigma = torch.zeros(M, dtype=torch.float32, device=dev)
+        if g_rgb is None:
+            g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        g_ambient, g_amb_abs = dense(g_ambient, (M, 2)), dense(g_amb_abs, (M,))
+        g_tx, g_tw = torch.zeros_like(tx), torch.zeros_like(tw)
+        grads = [torch.empty_like(w) for w in ws]
+        g_enc_a = torch.empty(audio_dim, dtype=torch.float32, device=dev)
+        g_eye = torch.empty(1, dtype=torch.float32, device=dev) if has_eye else None
+        g_ind = torch.empty(ind_dim, dtype=torch.float32, device=dev) if ind_dim else None
+        if M:
+            g_feat = torch.empty(2, 16, M, 2, dtype=torch.float32, device=dev)
+            hip.call("rn_train_head_backward", hip.ptr(g_sigma), hip.ptr(g_rgb), hip.ptr(g_ambient), hip.ptr(g_amb_abs), rgbs.data_ptr(),
+                     ambient.data_ptr(), M, hip.ptr(m_dev), hip.ptr(image), hip.ptr(work), g_feat[0].data_ptr(), g_feat[1].data_ptr(), s)
+            nw = _weights_desc(ws, audio_dim, has_eye, ind_dim)
+            hg = HeadGradsT()
+            (hg.amb_w0, hg.amb_w1, hg.amb_w2, hg.sig_w0, hg.sig_w1, hg.sig_w2, hg.col_w0, hg.col_w1) = [g.data_ptr() for g in grads]
+            hg.enc_a, hg.eye, hg.ind_code = g_enc_a.data_ptr(), hip.ptr(g_eye), hip.ptr(g_ind)
+            wsp = hip.workspace(int(_lib.rn_train_head_wgrad_workspace()), dev)
+            hip.call("rn_train_head_weight_grads", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), M, hip.ptr(m_dev), hip.ptr(work),
+                     C.byref(hg), hip.ptr(wsp), s)
+            gx, gw = _grid_desc(enc_x, tx), _grid_desc(enc_w, tw)
+            hip.call("rn_grid_scatter_lbc", g_feat[0].data_ptr(), xn.data_ptr(), M, hip.ptr(m_dev), C.byref(gx), hip.ptr(g_tx), s)
+            hip.call("rn_grid_scatter_lbc", g_feat[1].data_ptr(), wn.data_ptr(), M, hip.ptr(m_dev), C.byref(gw), hip.ptr(g_tw), s)
+        else:
+            for g in grads:
+                g.zero_()
+            g_enc_a.zero_()
+            if g_eye is not None:
+                g_eye.zero_()
+            if g_ind is not None:
+                g_ind.zero_()
+        return (None, None, g_enc_a.view(enc_a_shape), g_eye.view(eye_shape) if g_eye is not None else None,
+                g_ind.view(ind_shape) if g_ind is not None else None, None, None, g_tx, g_tw, *grads)
+
+
+def head_forward(model, xyzs, dirs, enc_a, ind_code, eye, m_dev=None):
+    """-> (sigma, rgb, ambient, ambient_abs): NeRFNetwork.forward + `ambient.abs().sum(-1)` (nerf/renderer.py:216) through the
+    fused training kernels.  m_dev: optional int32 device scalar, the number of live sample rows (the marcher's counter)."""
+    ws = _weights_of(model)
+    ind = ind_code if model.individual_dim > 0 else None
+    e = eye if model.exp_eye else None
+    return _HeadTrain.apply(xyzs, dirs, enc_a, e, ind, m_dev, (model.encoder, model.encoder_ambient, float(model.bound)),
+                            model.encoder.embeddings, model.encoder_ambient.embeddings, *ws)
+
+
+def usable(model, x, enc_a):
+    """Training call of the supported shape on the GPU in fp32 (autocast keeps the per-operator path)."""
+    import os
+    return (os.environ.get("RN_TRAIN_HEAD", "fused") == "fused" and x.is_cuda and torch.is_grad_enabled() and x.dim() == 2
+            and x.dtype == torch.float32 and not torch.is_autocast_enabled() and enc_a is not None and not x.requires_grad
+            and getattr(model, "_train_head_ok", None) is not False and _check(model))
+
+
+def _check(model):
+    ok = getattr(model, "_train_head_ok", None)
+    if ok is None:
+        ok = model._train_head_ok = supported(model)
+    return ok
+
+
+class _HeadLoss(torch.autograd.Function):
+    """Blend over the background, clamp and the head loss of Trainer.train_step in one kernel; returns (loss, pred)."""
+
+    @staticmethod
+    def forward(ctx, image, weights_sum, ambient, bg, target, face, w_amb):
+        N = image.shape[0]
+        dev = image.device
+        image, weights_sum, ambient = image.contiguous(), weights_sum.contiguous(), ambient.contiguous()
+        out = torch.empty(N * 8 + 1, dtype=torch.float32, device=dev)
+        loss, pred = out[N * 8:], out[0:3 * N].view(N, 3)
+        g_image, g_ws, g_amb = out[3 * N:6 * N].view(N, 3), out[6 * N:7 * N], out[7 * N:8 * N]
+        hip.call("rn_train_head_loss", hip.ptr(image), hip.ptr(weights_sum), hip.ptr(ambient), bg.data_ptr(), bg.stride(0), target.data_ptr(),
+                 target.stride(0), face.data_ptr(), face.stride(0), hip.ptr(w_amb), N, loss.data_ptr(), pred.data_ptr(), g_image.data_ptr(),
+                 g_ws.data_ptr(), g_amb.data_ptr(), hip.stream())
+        ctx.save_for_backward(out)
+        ctx.N = N
+        ctx.mark_non_differentiable(pred)
+        return loss.view(()), pred
+
+    @staticmethod
+    def backward(ctx, g, _g_pred):
+        (out,) = ctx.saved_tensors
+        N = ctx.N
+        scaled = out[3 * N:8 * N] * g            # one kernel for the three gradients
+        return scaled[0:3 * N].view(N, 3), scaled[3 * N:4 * N], scaled[4 * N:5 * N], None, None, None, None
+
+
+def loss_usable(*tensors):
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def head_loss(image, weights_sum, ambient, bg, target, face, w_amb):
+    """image [N,3], weights_sum [N], ambient [N] (composited), bg / target [N,3] and face [N] (0/1 floats; rows may be strided
+    views of one batch table), w_amb: device scalar.  -> (loss, pred [N,3])."""
+    def rows(t, width):
+        t = t.reshape(-1, width) if width > 1 else t.reshape(-1)
+        if t.dim() == 2 and t.stride(1) != 1:
+            t = t.contiguous()
+        return t
+    return _HeadLoss.apply(image, weights_sum, ambient, rows(bg, 3), rows(target, 3), rows(face, 1), w_amb.reshape(1))

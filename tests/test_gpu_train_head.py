@@ -1,0 +1,233 @@
+"""GPU parity of the fused training pass of the per-sample network (csrc/rn_train_head.hip, include/radnerf_train.h) against the
+per-operator path it replaces: NeRFNetwork.forward (nerf/network.py:222-283) over grid_encode / MLP / activation operators with
+torch.autograd, which tests/test_gpu_mlp_train.py, tests/test_gpu_ops.py and the reference-generated gradients of
+tests/test_golden_frames.py pin.  Also: the line-keyed table scatter against the operator's scatter, the one-kernel head loss
+against the PyTorch expression of nerf/utils.py:772-803, and the launch count of a whole training step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(size=32, **kw):
+    from radnerf.scene import SyntheticScene, default_opt
+    return SyntheticScene(H=size, W=size, n_frames=8, device="cuda", opt=default_opt(engine="ops", torso=False, smooth_lips=False, **kw))
+
+
+def _samples(M, seed, oob=7):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    xyzs = (torch.rand(M, 3, device="cuda", generator=g) * 2 - 1) * 0.98
+    xyzs[:oob] = 1.25                     # outside [-bound, bound]: zero features, no table gradient (gridencoder.cu:110-135)
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, device="cuda", generator=g), dim=-1)
+    enc_a = torch.randn(1, 64, device="cuda", generator=g) * 0.5
+    eye = torch.full((1, 1), 0.25, device="cuda")
+    return xyzs, dirs, enc_a, eye, g
+
+
+def _run(m, xyzs, dirs, enc_a, eye, index, up, mode, monkeypatch):
+    """forward + backward of NeRFNetwork.forward (+ |ambient| sum) under upstream gradients `up`; returns outputs and gradients."""
+    monkeypatch.setenv("RN_TRAIN_HEAD", mode)
+    for p in m.parameters():
+        p.grad = None
+    enc_a = enc_a.clone().requires_grad_(True)
+    eye = eye.clone().requires_grad_(True)
+    ind = m.individual_codes[index]
+    sigma, rgb, amb = m(xyzs, dirs, enc_a, ind, eye)
+    amb_abs = amb.abs().sum(-1)
+    loss = (sigma * up[0]).sum() + (rgb * up[1]).sum() + (amb_abs * up[2]).sum() + (amb * up[3]).sum()
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    grads["enc_a"], grads["eye"] = enc_a.grad.clone(), eye.grad.clone()
+    return (sigma.detach(), rgb.detach(), amb.detach()), grads
+
+
+@pytest.mark.parametrize("grid,M", [("tiledgrid16", 4099), ("hashgrid19", 12345)])
+def test_fused_head_matches_the_operator_path(hiplib, monkeypatch, grid, M):
+    kw = dict(xyz_grid="hashgrid", xyz_log2_hashmap_size=19) if grid == "hashgrid19" else {}
+    scene = _scene(32, **kw)
+    m = scene.model
+    m.train()
+    from radnerf import train_head
+    assert train_head.supported(m)
+    xyzs, dirs, enc_a, eye, g = _samples(M, 3)
+    up = [torch.randn(M, device="cuda", generator=g), torch.randn(M, 3, device="cuda", generator=g),
+          torch.randn(M, device="cuda", generator=g) * 0.3, torch.randn(M, 2, device="cuda", generator=g) * 0.3]
+    # The derivative of the 2-D grid with respect to the ambient coordinate is piecewise constant: a sample whose coordinate sits
+    # within rounding distance of a cell boundary of some level may take the neighbouring cell's derivative in one of the two
+    # paths (their ambient outputs differ by ~1e-6).  Such samples get zero upstream gradient in BOTH runs, so every remaining
+    # contribution is stable and all gradients are compared at the tight tolerance.
+    monkeypatch.setenv("RN_TRAIN_HEAD", "ops")
+    with torch.no_grad():
+        amb = m(xyzs, dirs, enc_a, m.individual_codes[3], eye)[2]
+    enc_w = m.encoder_ambient
+    scales = torch.tensor([2.0 ** (l * float(np.log2(enc_w.per_level_scale))) * enc_w.base_resolution - 1 for l in range(16)],
+                          dtype=torch.float64, device="cuda")
+    pos = ((amb.double() + 1) / 2).unsqueeze(-1) * scales + 0.5              # [M, 2, 16]
+    frac = pos - pos.floor()
+    margin = 2e-5 * scales                                                     # 2e-5 in normalised coordinates, per level
+    stable = ((frac > margin) & (frac < 1 - margin)).all(-1).all(-1)
+    assert 0.5 < float(stable.float().mean()) < 1.0
+    up = [u * (stable.float() if u.dim() == 1 else stable.float().unsqueeze(-1)) for u in up]
+    out_ops, g_ops = _run(m, xyzs, dirs, enc_a, eye, 3, up, "ops", monkeypatch)
+    out_fused, g_fused = _run(m, xyzs, dirs, enc_a, eye, 3, up, "fused", monkeypatch)
+    # forward: the inference kernel's arithmetic (sigma rel 2e-4, rgb / ambient abs 2e-5: DESIGN 3)
+    assert torch.allclose(out_fused[0], out_ops[0], rtol=2e-4, atol=1e-6)
+    assert torch.allclose(out_fused[1], out_ops[1], rtol=0, atol=2e-5)
+    assert torch.allclose(out_fused[2], out_ops[2], rtol=0, atol=2e-5)
+    assert set(g_fused) == set(g_ops)
+    for name in sorted(g_ops):
+        a, b = g_fused[name], g_ops[name]
+        assert a.shape == b.shape, name
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max()) / scale
+        cos = float(torch.nn.functional.cosine_similarity(a.reshape(1, -1).double(), b.reshape(1, -1).double()))
+        # Upstream of the 2-D grid every sample's contribution carries that grid's derivative (~2047 x table differences) and the
+        # contributions largely cancel in the sum, so ONE hidden unit whose pre-activation is within rounding distance of 0 (its
+        # ReLU derivative then differs between the two paths, ~2 of 1.3 M units per call) moves a gradient by ~1 % of its maximum.
+        upstream = name.startswith("ambient_net") or name in ("enc_a", "encoder.embeddings")
+        assert err < (3e-2 if upstream else 2e-3) and cos > (0.9999 if upstream else 0.99999), (name, err, cos)
+
+
+def test_fused_head_live_count_bounds_the_rows(hiplib):
+    """Rows past the device-side live count get no output and contribute no gradient (the zero rows behind the marcher's
+    counter, raymarching/raymarching.py:231-257)."""
+    scene = _scene(32)
+    m = scene.model
+    m.train()
+    from radnerf import train_head
+    M, live = 4096, 1500
+    xyzs, dirs, enc_a, eye, g = _samples(M, 5)
+    ind = m.individual_codes[0]
+
+    def run(x, d, m_dev):
+        for p in m.parameters():
+            p.grad = None
+        s, c, a, aa = train_head.head_forward(m, x, d, enc_a, ind, eye, m_dev=m_dev)
+        n = live
+        ((s[:n] ** 2).sum() + (c[:n] ** 2).sum() + aa[:n].sum()).backward()
+        return (s.detach().clone(), c.detach().clone(), aa.detach().clone()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    cnt = torch.tensor([live, 0], dtype=torch.int32, device="cuda")
+    out_a, g_a = run(xyzs, dirs, cnt)
+    out_b, g_b = run(xyzs[:live].contiguous(), dirs[:live].contiguous(), None)
+    assert torch.equal(out_a[0][:live], out_b[0]) and torch.equal(out_a[1][:live], out_b[1])
+    assert float(out_a[0][live:].abs().max()) == 0.0 and float(out_a[1][live:].abs().max()) == 0.0
+    for name in g_b:
+        scale = float(g_b[name].abs().max()) + 1e-12
+        assert float((g_a[name] - g_b[name]).abs().max()) / scale < 1e-4, name
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D):
+    """rn_grid_scatter_lbc == rn_grid_encode_backward's table gradient (kernel_grid_backward, gridencoder.cu:247-339)."""
+    import ctypes as C
+    import radnerf_hip as hip
+    from gridencoder import GridEncoder
+    from radnerf import train_head
+    from radnerf.fused import _grid_desc
+    enc = (GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048, gridtype="hash")
+           if D == 3 else GridEncoder(input_dim=2, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048,
+                                      gridtype="tiled")).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B = 20000
+    # ray-like clusters (runs of samples in the same coarse cell) + a few rows outside [0, 1]
+    base = torch.rand(B // 16, 1, D, device="cuda", generator=g)
+    x = (base + 0.02 * torch.arange(16, device="cuda").view(1, 16, 1) * torch.randn(B // 16, 1, D, device="cuda", generator=g)).reshape(-1, D)
+    x = x.clamp(0, 1)
+    x[:5] = 1.5
+    x = x.contiguous()
+    grad_lbc = torch.randn(16, B, 2, device="cuda", generator=g)
+    live = B - 37
+    cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+    got = torch.zeros_like(enc.embeddings)
+    gd = _grid_desc(enc, enc.embeddings)
+    hip.call("rn_grid_scatter_lbc", hip.ptr(grad_lbc), hip.ptr(x), B, hip.ptr(cnt), C.byref(gd), hip.ptr(got), hip.stream())
+    want = torch.zeros_like(enc.embeddings)
+    xl, gl = x[:live].contiguous(), grad_lbc[:, :live].contiguous()
+    hip.call("rn_grid_encode_backward", hip.ptr(gl), hip.ptr(xl), hip.ptr(enc.embeddings.detach()), hip.ptr(enc.offsets, torch.int32), hip.ptr(want),
+             live, D, 2, 16, float(np.log2(enc.per_level_scale)), 16, None, None, enc.gridtype_id, 0, 0, hip.RN_F32, hip.RN_LAYOUT_LBC, hip.stream())
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) / scale < 1e-5
+    assert int((got != 0).sum()) == int((want != 0).sum())
+
+
+def test_head_loss_kernel_matches_the_pytorch_expression(hiplib):
+    from radnerf import train_head
+    from radnerf.train import entropy_of
+    g = torch.Generator(device="cuda").manual_seed(2)
+    N = 4096
+    table = torch.rand(N, 15, device="cuda", generator=g)                # bg at columns 8:11, target 11:14, face 14 (SyntheticTrainStream)
+    table[:, 14] = (table[:, 14] > 0.5).float()
+    bg, target, face = table[:, 8:11], table[:, 11:14], table[:, 14]
+    image = (torch.rand(N, 3, device="cuda", generator=g) * 1.2 - 0.1).requires_grad_(True)     # some blends leave [0, 1]
+    ws = torch.rand(N, device="cuda", generator=g).requires_grad_(True)
+    with torch.no_grad():
+        ws[:4] = torch.tensor([0.0, 1.0, 1e-6, 1 - 1e-7], device="cuda")
+    amb = torch.rand(N, device="cuda", generator=g).requires_grad_(True)
+    w_amb = torch.tensor(0.037, device="cuda")
+    loss, pred = train_head.head_loss(image, ws, amb, bg, target, face, w_amb)
+    (loss * 1.7).backward()
+    got = (float(loss), pred.clone(), image.grad.clone(), ws.grad.clone(), amb.grad.clone())
+    image.grad = ws.grad = amb.grad = None
+    p2 = (image + (1 - ws).unsqueeze(-1) * bg).clamp(0, 1)
+    l2 = torch.nn.functional.mse_loss(p2, target, reduction="none").mean(-1).mean() + 1e-4 * entropy_of(ws).mean() + w_amb * (amb * (1 - face)).mean()
+    (l2 * 1.7).backward()
+    assert abs(got[0] - float(l2)) < 1e-6 * max(1.0, abs(float(l2)))
+    assert torch.allclose(got[1], p2, atol=1e-7)
+    assert torch.allclose(got[2], image.grad, rtol=1e-5, atol=1e-10)
+    assert torch.allclose(got[3], ws.grad, rtol=2e-5, atol=1e-9)
+    assert torch.allclose(got[4], amb.grad, rtol=1e-5, atol=1e-10)
+
+
+def _train_losses(monkeypatch, head, steps=6):
+    from radnerf.train import SyntheticTrainStream, Trainer
+    monkeypatch.setenv("RN_TRAIN_HEAD", head)
+    monkeypatch.setenv("RN_TRAIN_LOSS", "fused" if head == "fused" else "torch")
+    torch.manual_seed(0)
+    scene = _scene(64)
+    stream = SyntheticTrainStream(scene, n_rays=1024, seed=4)
+    trainer = Trainer(scene.model, scene.opt, update_extra_interval=0)
+    scene.model.mean_count = 0
+    import random
+    random.seed(0)
+    losses = [float(trainer.step(stream.batch())) for _ in range(steps)]
+    return losses, {n: p.detach().clone() for n, p in scene.model.named_parameters()}
+
+
+def test_training_steps_equal_the_operator_path(hiplib, monkeypatch):
+    """Six optimizer steps of Trainer (march -> network -> composite -> loss -> backward -> Adam) through the fused head and loss
+    kernels follow the per-operator steps."""
+    l_ops, p_ops = _train_losses(monkeypatch, "ops")
+    l_fused, p_fused = _train_losses(monkeypatch, "fused")
+    assert np.allclose(l_fused, l_ops, rtol=2e-4, atol=1e-7), (l_fused, l_ops)
+    for name in p_ops:
+        a, b = p_fused[name], p_ops[name]
+        # Adam normalises the step (eps = 1e-15): an entry whose gradient is at rounding level may move by lr either way, and
+        # everything upstream of the 2-D grid sees that grid's piecewise-constant derivative (see the test above) -- the
+        # parameters downstream of it must follow closely, the others stay within the steps' reach
+        moved = (a - b).abs()
+        assert float(moved.max()) <= 6 * 5e-3 + 1e-6, name
+        if name.startswith(("sigma_net", "color_net")):
+            assert float((moved > 2e-4).float().mean()) < 0.02, (name, float((moved > 2e-4).float().mean()))
+
+
+def test_training_step_launch_count(hiplib, monkeypatch):
+    """An eager training step is <= 40 kernel launches: counted with the profiler's kernel events."""
+    from radnerf.train import SyntheticTrainStream, Trainer
+    monkeypatch.setenv("RN_TRAIN_HEAD", "fused")
+    scene = _scene(64)
+    stream = SyntheticTrainStream(scene, n_rays=1024, seed=4)
+    trainer = Trainer(scene.model, scene.opt, update_extra_interval=0)
+    for _ in range(3):
+        trainer.step(stream.batch())
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        batch = stream.batch()
+        trainer.step(batch)
+        torch.cuda.synchronize()
+    kernels = [e for e in prof.events() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
+    names = [e.name for e in kernels]
+    print(len(names), "device activities:", sorted(set(names)))
+    assert 0 < len(names) <= 48, names
