@@ -79,7 +79,7 @@ int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, c
 /* Table gradient of one grid from level-major feature gradients: grad_table[row(l, corner)] += w_corner * grad[l, b, :]
  * (kernel_grid_backward, gridencoder.cu:247-339) for b < live count; inputs [M, D] normalised coordinates (rows outside
  * [0, 1] contribute nothing, gridencoder.cu:275-280).  grad_table [rows, 2] fp32 must be zeroed by the caller.  D = 2 / 3,
- * C = 2, fp32, align_corners = false, linear interpolation.  One workgroup merges the rows of 128 samples of one level per
+ * C = 2, fp32, align_corners = false, linear interpolation.  One workgroup merges the rows of 64 (D = 3) / 128 (D = 2) samples of one level per
  * 64-byte line of the table in LDS and issues one atomic request per touched line. */
 int rn_grid_scatter_lbc(const float *grad, const float *inputs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid,
                         float *grad_table, rn_stream_t stream);

@@ -800,7 +800,14 @@ __global__ void __launch_bounds__(256) k_train_const(CArgs p) {
 }
 
 // ---- table gradient -------------------------------------------------------------------------------------------------------
-constexpr uint32_t kScThreads = 256, kScSamples = 128, kScSlots = 1024, kScProbes = 24;
+#ifndef RN_SC_SLOTS
+#define RN_SC_SLOTS 512
+#endif
+// 256 threads = (256 / 2^(D-1)) samples x 2^(D-1) x-pairs of corners; 512 slots of 16 floats + key = 35 KB of LDS: four
+// workgroups per CU, so one workgroup's burst of atomics (its flush) runs under the others' loads and LDS inserts
+constexpr uint32_t kScThreads = 256, kScSlots = RN_SC_SLOTS, kScProbes = 24;
+constexpr uint32_t kScSlotBits = kScSlots == 1024 ? 10 : (kScSlots == 512 ? 9 : 8);
+static_assert((1u << kScSlotBits) == kScSlots, "slot count must be 256, 512 or 1024");
 constexpr uint32_t kScEmpty = 0xffffffffu;
 
 // Lanes hold (key, v[4]); consecutive lanes with equal keys form a run (ray-ordered samples stay in one coarse cell for many
@@ -833,7 +840,7 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__rest
                                                              uint32_t Mcap, const int32_t *__restrict__ m_dev, LevelConsts lc,
                                                              uint32_t gridtype) {
     constexpr uint32_t P = 1u << (D - 1);            // x-pairs of corners per sample
-    constexpr uint32_t PT = P / 2;                   // pairs per thread: the 128 samples take lanes 0..127 and 128..255
+    constexpr uint32_t kScSamples = kScThreads / P;  // lanes 0 .. S-1: pair 0 of the S samples, lanes S .. 2S-1: pair 1, ...
     __shared__ uint32_t keys[kScSlots];
     __shared__ __attribute__((aligned(16))) float vals[kScSlots * 16];
     const uint32_t M = live_count(Mcap, m_dev);
@@ -846,7 +853,7 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__rest
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
     float *gg = grad_grid + (size_t)off * 2;
     const uint32_t b = blockIdx.x * kScSamples + (threadIdx.x & (kScSamples - 1u));
-    const uint32_t pset = threadIdx.x / kScSamples;   // which half of the x-pairs
+    const uint32_t q = threadIdx.x / kScSamples;      // this thread's x-pair: bits of q = the y (, z) corner
     float in[D];
     bool live = b < M;
 #pragma unroll
@@ -860,9 +867,7 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__rest
     float2 g = make_float2(0.0f, 0.0f);
     if (live) g = *reinterpret_cast<const float2 *>(grad + ((size_t)level * Mcap + b) * 2);
     const uint32_t resolution = lc.resolution[level];
-#pragma unroll
-    for (uint32_t t = 0; t < PT; t++) {
-        const uint32_t q = pset * PT + t;             // bits of q: the y (, z) corner
+    {
         uint32_t pgl[D];
         pgl[0] = pos_grid[0];
         float wyz[2] = {1.0f - pos[0], pos[0]};       // the reference multiplies the x term first (gridencoder.cu:298-308)
@@ -886,7 +891,7 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__rest
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const uint32_t line = rows[e] >> 3, sub = rows[e] & 7u;
-                uint32_t slot = (line * 2654435761u) >> 22;   // 10 bits
+                uint32_t slot = (line * 2654435761u) >> (32u - kScSlotBits);
                 bool placed = false;
                 for (uint32_t probe = 0; probe < kScProbes; probe++) {
                     const uint32_t prev = atomicCAS(&keys[slot], kScEmpty, line);
@@ -1092,7 +1097,7 @@ int rn_grid_scatter_lbc(const float *grad, const float *inputs, uint32_t M, cons
     RN_REQUIRE((grid->D == 2 || grid->D == 3) && grid->L >= 1 && grid->L <= kMaxLevels, "grid_scatter_lbc: D must be 2 or 3, L <= 32");
     RN_REQUIRE(((uintptr_t)grad_table & 63u) == 0 && ((uintptr_t)grad & 7u) == 0, "grid_scatter_lbc: grad_table must be 64-byte, grad 8-byte aligned");
     const LevelConsts lc = make_level_consts(grid->L, grid->S, grid->H);
-    const dim3 g(div_up(M, kScSamples), grid->L);
+    const dim3 g(div_up(M, kScThreads >> (grid->D - 1)), grid->L);
     if (grid->D == 3)
         hipLaunchKernelGGL(k_grid_scatter<3>, g, dim3(kScThreads), 0, as_stream(stream), grad, inputs, grid->offsets, grad_table, M, m_dev, lc, grid->gridtype);
     else

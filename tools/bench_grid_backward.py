@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--B", type=int, default=58000)
     args = ap.parse_args()
     import radnerf_hip as hip
+    from radnerf import train_head  # noqa: F401  (declares the argument types of rn_grid_scatter_lbc)
     from gridencoder.encoder import level_offsets
     out = {}
     for name, (D, log2T, gridtype) in {"xyz hash T=2^19": (3, 19, 0), "ambient tiled T=2^16": (2, 16, 1)}.items():
@@ -40,15 +41,23 @@ def main():
             ge = torch.zeros_like(emb)
             fn = lambda: hip.call("rn_grid_encode_backward", hip.ptr(g), hip.ptr(x), hip.ptr(emb), hip.ptr(off_d), hip.ptr(ge), B, D, C, L, S, 16,
                                   None, None, gridtype, 0, 0, hip.RN_F32, hip.RN_LAYOUT_BLC, hip.stream())
-            for _ in range(3):
-                fn()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(20):
-                fn()
-            b.record()
-            torch.cuda.synchronize()
-            res[pts + " us"] = round(a.elapsed_time(b) / 20 * 1e3, 1)
+            # round 3: the line-keyed scatter of the fused training pass (level-major gradients, rn_grid_scatter_lbc)
+            import ctypes as C_
+            from radnerf.fused import GridT
+            gd = GridT()
+            gd.embeddings, gd.offsets, gd.D, gd.L, gd.H, gd.S, gd.gridtype, gd.dtype = emb.data_ptr(), off_d.data_ptr(), D, L, 16, S, gridtype, hip.RN_F32
+            g_lbc = g.view(B, L, C).permute(1, 0, 2).contiguous()
+            fn2 = lambda: hip.call("rn_grid_scatter_lbc", hip.ptr(g_lbc), hip.ptr(x), B, None, C_.byref(gd), hip.ptr(ge), hip.stream())
+            for label, f in (("", fn), (" line-keyed", fn2)):
+                for _ in range(3):
+                    f()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20):
+                    f()
+                b.record()
+                torch.cuda.synchronize()
+                res[pts + label + " us"] = round(a.elapsed_time(b) / 20 * 1e3, 1)
         out[name] = res
     print(json.dumps(out))
 

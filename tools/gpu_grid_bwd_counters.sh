@@ -11,8 +11,8 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_grid_bwd" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "k_grid_bwd" in r["Kernel_Name"] or "k_grid_scatter" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} | {"launches": max(len(v) for v in cs.values())} for k, cs in agg.items()}
 out["timing"] = json.load(open("$O/timing.json"))
 json.dump(out, open("$O/counters.json", "w"), indent=1)
