@@ -29,8 +29,9 @@ def load_checkpoint(model, checkpoint, map_location=None, optimizer=None, half_t
 
     optimizer: restored from the checkpoint's `optimizer` entry when it has one (full checkpoints, :1320-1325); a state that
     does not fit (another parameter grouping) is skipped, as the reference does (:1408-1413).
-    half_tables: build the persistent fp16 copies of the three grid tables now (GridEncoder.half_table) -- what the
-    reference's `-O` mode re-creates by casting every table on every call (gridencoder/grid.py:43-44).
+    half_tables: build the persistent fp16 copies of the three grid tables now (GridEncoder.half_table) and make the fused
+    inference engine read them (model.opt.half_tables) -- what the reference's `-O` mode re-creates by casting every table on
+    every call (gridencoder/grid.py:43-44).  The copies follow the parameters: they are re-cast when a table's version changes.
     `model.checkpoint_meta` receives epoch / global_step / stats when the file has them."""
     if not isinstance(checkpoint, dict):
         checkpoint = torch.load(checkpoint, map_location=map_location, weights_only=False)
@@ -52,6 +53,8 @@ def load_checkpoint(model, checkpoint, map_location=None, optimizer=None, half_t
     if getattr(model, "enc_a", None) is not None:
         model.enc_a = None  # the lip-smoothing state belongs to a stream, not to the weights
     if half_tables:
+        if getattr(model, "opt", None) is not None:
+            model.opt.half_tables = True          # the fused engine then reads the fp16 copies (radnerf/fused.py: FusedState.refresh)
         for name in ("encoder", "encoder_ambient", "torso_encoder"):
             enc = getattr(model, name, None)
             if enc is not None and hasattr(enc, "half_table"):

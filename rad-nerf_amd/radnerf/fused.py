@@ -161,7 +161,11 @@ class FusedState:
         # "f32x2": fp32-grade products from two fp16 halves per operand on the same matrix cores (include/radnerf_fused.h)
         mlp = {"f32": hip.RN_F32, "f16": hip.RN_F16, "f32x2": RN_F32_SPLIT}[
             getattr(getattr(self.model, "opt", None), "mlp_dtype", "f32")]
-        versions = tuple((w._version, w.data_ptr()) for w in ws + tables) + (mlp,)
+        # opt.half_tables (load_checkpoint(half_tables=True) sets it): the kernels read persistent fp16 copies of the grid tables
+        # (GridEncoder.half_table, re-cast only when the parameter changes) -- the reference's -O mode casts every table on every
+        # call (gridencoder/grid.py:43-44: 7.2 + 4.4 + 4.4 MB per loop iteration)
+        half = bool(getattr(getattr(self.model, "opt", None), "half_tables", False))
+        versions = tuple((w._version, w.data_ptr()) for w in ws + tables) + (mlp, half)
         if versions == self._versions:
             return
         m = self.model
@@ -185,8 +189,12 @@ class FusedState:
             self.tw.ind_dim = m.individual_dim_torso
             assert tuple(ws[8].shape) == (64, 96 + m.individual_dim_torso) and tuple(ws[11].shape) == (32, 128 + m.individual_dim_torso)
             hip.call("rn_torso_pack_weights", C.byref(self.tw), hip.ptr(self.tpacked), hip.stream())
-        # tables: fp32 parameters are read in place (fp16 copies are a separate, opt-in mode)
-        self.tables = [hip.aligned(t.detach()) for t in tables]
+        # tables: fp32 parameters are read in place; with opt.half_tables their persistent fp16 copies
+        if half:
+            encs = [m.encoder, m.encoder_ambient] + ([m.torso_encoder] if m.torso else [])
+            self.tables = [hip.aligned(e.half_table()) for e in encs]
+        else:
+            self.tables = [hip.aligned(t.detach()) for t in tables]
         self.gx = _grid_desc(m.encoder, self.tables[0])
         self.gw = _grid_desc(m.encoder_ambient, self.tables[1])
         self.gt = _grid_desc(m.torso_encoder, self.tables[2]) if m.torso else None

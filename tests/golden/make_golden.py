@@ -1,6 +1,6 @@
 """Generates the golden fixtures under tests/golden/ -- run ONLY in the build container (needs /root/reference).
 
-    python tests/golden/make_golden.py            # reference_flow.npz, reference_ops.npz, reference_frames.npz
+    python tests/golden/make_golden.py            # reference_flow.npz, reference_ops.npz, reference_frames.npz, reference_mixed.npz
 
 What runs is the reference's OWN Python, imported unmodified from /root/reference:
   * the operator wrappers raymarching/raymarching.py, gridencoder/grid.py, shencoder/sphere_harmonics.py,
@@ -361,10 +361,90 @@ def make_frames(env):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- reference_mixed.npz
+class reference_autocast:
+    """The reference's `-O` mode (main.py:111-120: fp16 + cuda_ray) as Trainer.test runs it: the whole test_step under
+    `torch.cuda.amp.autocast(enabled=True)` (nerf/utils.py:944).  On this CPU-only box that context disables itself, so the
+    same two switches are set by hand: (1) the legacy CUDA autocast flag, which is what the reference's own code looks at --
+    `torch.is_autocast_enabled()` in gridencoder/grid.py:41-44 (half table, half outputs) and the
+    `@custom_fwd(cast_inputs=torch.float32)` of raymarching / shencoder / freqencoder / activation.trunc_exp (fp32 inputs,
+    autocast off inside); (2) torch's CPU autocast in float16, which makes nn.Linear / nn.Conv1d of the unmodified
+    nerf/network.py run in fp16 with fp32-promoting `cat`, exactly the op classes CUDA autocast lowers / promotes."""
+
+    def __enter__(self):
+        import torch.amp.autocast_mode as am
+        self.cpu = torch.autocast("cpu", dtype=torch.float16)
+        self.cpu.__enter__()
+        torch.set_autocast_enabled(True)
+        assert torch.is_autocast_enabled() and torch.is_autocast_enabled("cpu")
+        # custom_fwd(cast_inputs=float32) casts the floating-point tensors that live on ITS device ("cuda"); here every tensor
+        # stands in for a CUDA tensor (the `.cuda()` hops are the identity), so CPU tensors are cast too
+        self.am, self.cast = am, am._cast
+        am._cast = lambda value, device_type, dtype: self.cast(value, "cpu" if device_type == "cuda" else device_type, dtype)
+        return self
+
+    def __exit__(self, *exc):
+        self.am._cast = self.cast
+        torch.set_autocast_enabled(False)
+        return self.cpu.__exit__(*exc)
+
+
+def make_mixed(env):
+    """NeRFNetwork.forward / forward_torso / density and whole frames of the UNMODIFIED reference under fp16 autocast."""
+    SyntheticScene, default_opt, rm, gridencoder, _, _, ref_network, ref_utils = env
+    out = {}
+    flow = np.load(os.path.join(HERE, "reference_flow.npz"))
+    opt = default_opt()
+    torch.manual_seed(0)
+    scene = SyntheticScene(H=32, W=32, n_frames=8, device="cpu", opt=opt, model=ref_network.NeRFNetwork(opt))
+    m = scene.model
+    x, d, xy = (torch.from_numpy(flow[k]) for k in ("net_x", "net_d", "torso_xy"))
+    f = scene.frame(0)            # the loader's work (rays, windows) happens outside the autocast region (nerf/utils.py:934-946)
+    with torch.no_grad(), reference_autocast():
+        enc_a0 = m.encode_audio(f["auds"])
+        c, ct = m.individual_codes[0], m.individual_codes_torso[0]
+        sigma, color, amb = m(x, d, enc_a0, c, scene.eye)
+        dens = m.density(x, enc_a0, scene.eye)["sigma"]
+        ta, tc, tdx = m.forward_torso(xy, scene.poses6[0:1], enc_a0, ct)
+    out["dtypes"] = np.array([f"{n}:{t.dtype}" for n, t in (("enc_a", enc_a0), ("sigma", sigma), ("color", color), ("ambient", amb),
+                                                            ("torso_alpha", ta), ("torso_color", tc), ("torso_dx", tdx))])
+    out.update(net_enc_a=t2n(enc_a0.float()), net_sigma=t2n(sigma.float()), net_color=t2n(color.float()), net_ambient=t2n(amb.float()),
+               net_density=t2n(dens.float()), torso_alpha=t2n(ta.float()), torso_color=t2n(tc.float()), torso_dx=t2n(tdx.float()))
+    # the same calls with autocast off but the SAME audio code: isolates what the 16-bit layers change
+    with torch.no_grad():
+        s32, c32, a32 = m(x, d, enc_a0.float(), c, scene.eye)
+    out.update(net_sigma_fp32=t2n(s32), net_color_fp32=t2n(c32), net_ambient_fp32=t2n(a32))
+
+    # ---- a 32 x 32 frame of the shipped (tiled) model and a 64 x 64 frame of the hash T = 2^19 model through run_cuda
+    kw = {"dt_gamma": opt.dt_gamma, "max_steps": opt.max_steps}
+    m.enc_a = None
+    f = scene.frame(0)
+    with torch.no_grad(), reference_autocast():
+        res = m.render(f["rays_o"], f["rays_d"], f["auds"], f["bg_coords"], f["poses"], eye=f["eye"], index=0, bg_color=f["bg_color"],
+                       staged=True, perturb=False, **kw)
+    out["tiled16_frame0_image"] = t2n(res["image"].float()).reshape(-1, 3)
+    out["tiled16_frame0_depth"] = t2n(res["depth"].float()).reshape(-1)
+    out["tiled16_frame0_enc_a"] = t2n(m.enc_a.float())
+    del scene, m
+    opt = default_opt()
+    torch.manual_seed(0)
+    scene = cases.swap_in_hash19(SyntheticScene, opt, gridencoder.GridEncoder, 64, 64, model=ref_network.NeRFNetwork(opt))
+    m = scene.model
+    m.enc_a = None
+    f = scene.frame(0)
+    with torch.no_grad(), reference_autocast():
+        res = m.render(f["rays_o"], f["rays_d"], f["auds"], f["bg_coords"], f["poses"], eye=f["eye"], index=0, bg_color=f["bg_color"],
+                       staged=True, perturb=False, **kw)
+    out["hash19_frame0_image"] = t2n(res["image"].float()).reshape(-1, 3)
+    out["hash19_frame0_depth"] = t2n(res["depth"].float()).reshape(-1)
+    out["hash19_frame0_enc_a"] = t2n(m.enc_a.float())
+    return out
+
+
 def main():
     env = install_reference()
-    todo = sys.argv[1:] or ["flow", "ops", "frames"]
-    for name, fn in (("flow", make_flow), ("ops", make_ops), ("frames", make_frames)):
+    todo = sys.argv[1:] or ["flow", "ops", "frames", "mixed"]
+    for name, fn in (("flow", make_flow), ("ops", make_ops), ("frames", make_frames), ("mixed", make_mixed)):
         if name in todo:
             out = fn(env)
             path = os.path.join(HERE, f"reference_{name}.npz")

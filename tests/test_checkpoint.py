@@ -1,6 +1,7 @@
 """Reference checkpoint format (nerf/utils.py:1302-1396): round trip through this tree's NeRFNetwork."""
 import os
 
+import pytest
 import torch
 
 
@@ -67,3 +68,48 @@ def test_full_checkpoint_restores_optimizer_and_meta(hiplib, tmp_path):
     assert b.checkpoint_meta["epoch"] == 3 and b.checkpoint_meta["global_step"] == 77 and b.checkpoint_meta["optimizer_loaded"]
     sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
     assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)
+
+
+@pytest.mark.gpu
+def test_half_tables_checkpoint_feeds_the_fused_engine(hiplib, tmp_path):
+    """load_checkpoint(half_tables=True) builds persistent fp16 copies of the three grid tables and the fused
+    engine renders from them; frames equal, bit for bit, those rendered from tables cast anew on every call (what the
+    reference's -O mode does, gridencoder/grid.py:43-44), the copies are not re-made while the parameters stand still, and
+    they follow an in-place update of the parameters."""
+    from radnerf.checkpoint import load_checkpoint, save_checkpoint
+    from radnerf.scene import SyntheticScene, default_opt
+
+    def scene(seed):
+        return SyntheticScene(H=48, W=48, n_frames=8, device="cuda", opt=default_opt(engine="fused", mlp_dtype="f16"), seed=seed)
+    src = scene(0)
+    path = save_checkpoint(src.model, os.path.join(tmp_path, "ngp.pth"))
+    a, b = scene(3), scene(4)
+    for s in (a, b):
+        missing, unexpected = load_checkpoint(s.model, path, map_location="cuda", half_tables=True)
+        assert missing == [] and unexpected == [] and s.model.opt.half_tables
+    encs = lambda m: (m.encoder, m.encoder_ambient, m.torso_encoder)  # noqa: E731
+    assert all(e._half is not None and e._half[1].dtype == torch.float16 for e in encs(a.model))
+    kept = [e._half[1] for e in encs(a.model)]
+
+    def frame(s, i, recast):
+        if recast:                                   # the reference's behaviour: a fresh cast of every table for this call
+            for e in encs(s.model):
+                e._half = None
+        with torch.no_grad():
+            return s.render(i)["image"].clone()
+    for i in (0, 1):
+        fa, fb = frame(a, i, False), frame(b, i, True)
+        assert torch.equal(fa, fb)
+    assert all(e._half[1] is k for e, k in zip(encs(a.model), kept)), "persistent copies were re-made without a parameter change"
+    from radnerf import fused
+    st = fused._state(a.model)
+    assert st.tables[0].dtype == torch.float16 and st.gx.dtype == hiplib.RN_F16 and st.gt.dtype == hiplib.RN_F16
+    # an in-place parameter update (the optimizer's) re-makes the copies
+    with torch.no_grad():
+        for s in (a, b):
+            s.model.encoder.embeddings.mul_(1.25)
+            s.model.enc_a = None
+    b.model.enc_a = None
+    f2a, f2b = frame(a, 0, False), frame(b, 0, True)
+    assert torch.equal(f2a, f2b)
+    assert a.model.encoder._half[1] is not kept[0]

@@ -129,3 +129,150 @@ def test_reference_style_calls_through_the_backend(po, hiplib, rng, binding):
     fq = torch.empty(1000, 3 + 3 * 2 * 4, device=dev)
     freqencoder_backend.freq_encode_forward(v, 1000, 3, 4, 27, fq)
     np.testing.assert_allclose(fq.cpu().numpy(), po.freq_encode_forward(d[:1000], 4), rtol=0, atol=4e-5)
+
+
+@pytest.mark.gpu
+def test_all_19_pybind_functions_reproduce_the_reference_vectors(po, hiplib):
+    """Every function of the four built pybind11 modules (raymarching/src/bindings.cpp:5-21, gridencoder/src/bindings.cpp,
+    shencoder/src/bindings.cpp, freqencoder/src/bindings.cpp), called with CUDA tensors allocated the way the reference's
+    wrappers allocate them (raymarching/raymarching.py:42-45, 231-244, 301-305, 323-326, 385-395; gridencoder/grid.py:47-54,
+    77-84; shencoder/sphere_harmonics.py:24-32, 48-52; freqencoder/freq.py:26-28, 44-47), on the inputs of
+    tests/golden/reference_ops.npz -- vectors those wrappers themselves produced (tests/golden/make_golden.py)."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import cases
+    from radnerf.scene import SyntheticScene, default_opt
+    mods = _pybind_modules(hiplib)
+    rmb, geb, shb, fqb = mods["_raymarching_face"], mods["_gridencoder"], mods["_shencoder"], mods["_freqencoder"]
+    gold = np.load(os.path.join(here, "golden", "reference_ops.npz"), allow_pickle=False)
+    flow = np.load(os.path.join(here, "golden", "reference_flow.npz"))
+    dev = "cuda"
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)  # noqa: E731
+    cpu = lambda t: t.detach().float().cpu().numpy() if t.dtype in (torch.float16, torch.float32) else t.detach().cpu().numpy()  # noqa: E731
+    called = set()
+
+    def call(mod, name, *a):
+        called.add(name)
+        getattr(mod, name)(*a)
+
+    scene = SyntheticScene(H=32, W=32, n_frames=8, device=dev, opt=default_opt())
+    m, opt = scene.model, scene.opt
+    rays_o = torch.from_numpy(flow["rays_o"]).reshape(-1, 3).contiguous().to(dev)
+    rays_d = torch.from_numpy(flow["rays_d"]).reshape(-1, 3).contiguous().to(dev)
+    N = rays_o.shape[0]
+    bits = m.density_bitfield
+    # ---- _raymarching_face: 12 functions
+    nears, fars = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    call(rmb, "near_far_from_aabb", rays_o, rays_d, m.aabb_infer, N, m.min_near, nears, fars)
+    assert np.array_equal(cpu(nears), gold["nears"]) and np.array_equal(cpu(fars), gold["fars"])
+    coords = torch.empty(N, 2, device=dev)
+    call(rmb, "sph_from_ray", rays_o, rays_d, 2.0, N, coords)
+    np.testing.assert_allclose(cpu(coords), po.sph_from_ray(cpu(rays_o), cpu(rays_d), 2.0), rtol=0, atol=2e-6)
+    mc = T("morton_coords")
+    idx = torch.empty(mc.shape[0], dtype=torch.int32, device=dev)
+    call(rmb, "morton3D", mc, mc.shape[0], idx)
+    assert np.array_equal(cpu(idx), gold["morton_indices"])
+    back = torch.empty(mc.shape[0], 3, dtype=torch.int32, device=dev)
+    call(rmb, "morton3D_invert", idx, mc.shape[0], back)
+    assert np.array_equal(cpu(back), gold["morton_invert"])
+    grid = T("occ_grid")
+    Cc, H3 = grid.shape
+    bitfield = torch.empty(Cc * H3 // 8, dtype=torch.uint8, device=dev)
+    call(rmb, "packbits", grid, Cc * H3, 1.0, bitfield)
+    assert np.array_equal(cpu(bitfield), gold["occ_bits"])
+    dil = torch.empty_like(grid)
+    call(rmb, "morton3D_dilation", grid, Cc, int(round(H3 ** (1 / 3))), dil)
+    assert np.array_equal(cpu(dil), gold["occ_dilated"])
+    # march_rays (raymarching.py:380-395): M = n_alive * n_step, then M += 128 - M % 128; zero-initialised outputs
+    alive3 = T("march3_alive")
+    n_alive, n_step = alive3.shape[0], 3
+    M = n_alive * n_step
+    M += 128 - M % 128
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+    rays_t = nears.clone()
+    call(rmb, "march_rays", n_alive, n_step, alive3, rays_t, rays_o, rays_d, m.bound, opt.dt_gamma, opt.max_steps, m.cascade, m.grid_size, bits,
+         nears, fars, xyzs, dirs, deltas, torch.zeros(n_alive, device=dev))
+    for got, key in ((xyzs, "march3_xyzs"), (dirs, "march3_dirs"), (deltas, "march3_deltas")):
+        assert np.array_equal(cpu(got), gold[key]), key
+    ws, dp, im = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+    alive_c = alive3.clone()
+    call(rmb, "composite_rays", n_alive, n_step, 1e-4, alive_c, rays_t, T("comp_sigmas"), T("comp_rgbs"), deltas, ws, dp, im)
+    assert np.array_equal(cpu(alive_c), gold["comp_rays_alive"]) and np.array_equal(cpu(rays_t), gold["comp_rays_t"])
+    np.testing.assert_allclose(cpu(ws), gold["comp_weights_sum"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(cpu(im), gold["comp_image"], rtol=0, atol=2e-5)
+    # march_rays_train, first epochs (raymarching.py:221-257): M = N * max_steps, outputs trimmed to counter[0] padded
+    Mt = N * opt.max_steps
+    xt, dt_, dlt = torch.zeros(Mt, 3, device=dev), torch.zeros(Mt, 3, device=dev), torch.zeros(Mt, 2, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    call(rmb, "march_rays_train", rays_o, rays_d, bits, m.bound, opt.dt_gamma, opt.max_steps, N, m.cascade, m.grid_size, Mt, nears, fars, xt, dt_,
+         dlt, rays, counter, torch.zeros(N, device=dev))
+    mcount = int(counter[0].item())
+    mcount += 128 - mcount % 128
+    xt, dt_, dlt = xt[:mcount], dt_[:mcount], dlt[:mcount]
+    for got, key in ((xt, "train_xyzs"), (dt_, "train_dirs"), (dlt, "train_deltas"), (rays, "train_rays")):
+        assert np.array_equal(cpu(got), gold[key]), key
+    g_o, g_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
+    call(rmb, "march_rays_train_backward", T("trainb_gx"), T("trainb_gd"), rays, dlt.contiguous(), N, mcount, g_o, g_d)
+    np.testing.assert_allclose(cpu(g_o), gold["trainb_grad_rays_o"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(cpu(g_d), gold["trainb_grad_rays_d"], rtol=1e-5, atol=1e-3)
+    sg, rg, am = T("ctrain_sigmas"), T("ctrain_rgbs"), T("ctrain_ambient")
+    wsum, asum, dep, img = (torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev))
+    call(rmb, "composite_rays_train_forward", sg, rg, am, dlt.contiguous(), rays, mcount, N, 1e-4, wsum, asum, dep, img)
+    for got, key, tol in ((wsum, "ctrain_weights_sum", 3e-5), (asum, "ctrain_ambient_sum", 3e-5), (dep, "ctrain_depth", 2e-4), (img, "ctrain_image", 3e-5)):
+        np.testing.assert_allclose(cpu(got), gold[key], rtol=0, atol=tol, err_msg=key)
+    gs, gr, ga = torch.zeros_like(sg), torch.zeros_like(rg), torch.zeros_like(am)
+    call(rmb, "composite_rays_train_backward", T("ctrain_g_ws"), T("ctrain_g_as"), T("ctrain_g_im"), sg, rg, am, dlt.contiguous(), rays, wsum, asum,
+         img, mcount, N, 1e-4, gs, gr, ga)
+    for got, key in ((gs, "ctrain_grad_sigmas"), (gr, "ctrain_grad_rgbs"), (ga, "ctrain_grad_ambient")):
+        np.testing.assert_allclose(cpu(got), gold[key], rtol=0, atol=2e-4, err_msg=key)
+    # ---- _gridencoder: 3 functions (grid.py:27-89: [L,B,C] outputs, permuted by the wrapper; [L,B,C] gradients in)
+    from gridencoder import GridEncoder
+    for name, seed in (("hash3d", 100 + len("hash3d")), ("tiled2d", 100 + len("tiled2d"))):
+        kw, x, grad = cases.grid_case(name)
+        enc = cases.redraw_table(GridEncoder(**kw), seed).to(dev)
+        D, L, C = kw["input_dim"], kw["num_levels"], kw["level_dim"]
+        B = x.shape[0]
+        S, Hb = float(np.log2(enc.per_level_scale)), enc.base_resolution
+        xin = ((x + 1) / 2).to(dev).contiguous()                                   # GridEncoder.forward, bound = 1 (grid.py:151)
+        emb = enc.embeddings.detach()
+        out = torch.empty(L, B, C, device=dev)
+        dy_dx = torch.empty(B, L * D * C, device=dev) if name == "tiled2d" else None
+        call(geb, "grid_encode_forward", xin, emb, enc.offsets, out, B, D, C, L, S, Hb, dy_dx, enc.gridtype_id, False, 0)
+        assert np.array_equal(cpu(out.permute(1, 0, 2).reshape(B, L * C)), gold[f"grid_{name}_out"]), name
+        g = grad.to(dev).view(B, L, C).permute(1, 0, 2).contiguous()               # grid.py:75
+        g_emb = torch.zeros_like(emb)
+        g_in = torch.zeros(B, D, device=dev) if dy_dx is not None else None
+        call(geb, "grid_encode_backward", g, xin, emb, enc.offsets, g_emb, B, D, C, L, S, Hb, dy_dx, g_in, enc.gridtype_id, False, 0)
+        np.testing.assert_allclose(cpu(g_emb), gold[f"grid_{name}_grad_table"], rtol=1e-5, atol=1e-5)
+        if g_in is not None:
+            np.testing.assert_allclose(cpu(g_in) / 2, gold[f"grid_{name}_grad_inputs"], rtol=1e-5, atol=2e-4)   # d/dx of (x + 1) / 2
+    kw, x, _ = cases.grid_case("tv3d")
+    enc = cases.redraw_table(GridEncoder(**kw), 77).to(dev)
+    g_tv = torch.zeros_like(enc.embeddings)
+    xin = ((x + 1) / 2).to(dev).contiguous()
+    call(geb, "grad_total_variation", xin, enc.embeddings.detach(), g_tv, enc.offsets, 1e-3, x.shape[0], 3, 2, kw["num_levels"],
+         float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, False)
+    np.testing.assert_allclose(cpu(g_tv), gold["grid_tv3d_grad"], rtol=1e-4, atol=1e-7)
+    # ---- _shencoder, _freqencoder: 2 + 2 functions
+    d, g = cases.dir_case()
+    din, B = d.to(dev), d.shape[0]
+    sh, dy = torch.empty(B, 16, device=dev), torch.empty(B, 3 * 16, device=dev)
+    call(shb, "sh_encode_forward", din, sh, B, 3, 4, dy)
+    np.testing.assert_allclose(cpu(sh), gold["sh_out"], rtol=0, atol=2e-6)
+    g_in = torch.zeros(B, 3, device=dev)
+    call(shb, "sh_encode_backward", g.to(dev), din, B, 3, 4, dy, g_in)
+    np.testing.assert_allclose(cpu(g_in), gold["sh_grad_inputs"], rtol=1e-5, atol=2e-5)
+    for D, deg in ((2, 10), (6, 4)):
+        x, g = cases.freq_case(D, deg)
+        xin, B, C = x.to(dev), x.shape[0], D + D * 2 * deg
+        y = torch.empty(B, C, device=dev)
+        call(fqb, "freq_encode_forward", xin, B, D, deg, C, y)
+        np.testing.assert_allclose(cpu(y), gold[f"freq{D}_out"], rtol=0, atol=2e-6 * 2 ** deg)
+        g_in = torch.zeros(B, D, device=dev)
+        call(fqb, "freq_encode_backward", g.to(dev), y, B, D, deg, C, g_in)
+        np.testing.assert_allclose(cpu(g_in), gold[f"freq{D}_grad_inputs"], rtol=1e-4, atol=2e-3 * 2 ** deg)
+    want = {fn for fns in REFERENCE_SURFACE.values() for fn in fns}
+    assert called == want and len(called) == 19, want ^ called
