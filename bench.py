@@ -492,10 +492,12 @@ def main():
                                          "trace's 31 % of rays hitting the head at this pose"},
                        "audio_batch": args.audio_batch if engine == "fused" and not tile else 0,
                        "frames_in_flight": getattr(fpr, "n_streams", 1), "loop_launch": getattr(scene.opt, "loop_launch", "split"),
-                       "collectives": ({"per_frame": 1, "kind": "all_gather of uint8 band rows (+ 68 B of loop counts that verify the band-local "
-                                        "step schedules)", "schedule": getattr(fpr, "schedule", None), "frames_redone_exactly": getattr(fpr, "redone", 0)}
-                                       if tile else {"per_frame": 1.0 / max(getattr(fpr, "gather_every", 1), 1), "kind": "gather of uint8 frames to rank 0, "
-                                                     f"{getattr(fpr, 'gather_every', 1)} frames per collective"}) if world > 1 else None,
+                       "collectives": (dict({"per_frame": 1, "kind": "gather of uint8 band rows to rank 0 (+ 68 B of loop counts that verify the "
+                                             "band-local step schedules; the verdicts return in one broadcast per finish())",
+                                             "schedule": getattr(fpr, "schedule", None), "frames_redone_exactly": getattr(fpr, "redone", 0)}
+                                            if tile else {"per_frame": 1.0 / max(getattr(fpr, "gather_every", 1), 1), "kind": "gather of uint8 frames to rank 0, "
+                                                          f"{getattr(fpr, 'gather_every', 1)} frames per collective"},
+                                            backend=dist.get_backend(), world_seen_by_backend=dist.get_world_size())) if world > 1 else None,
                        "loop_iterations_enqueued": (getattr(scene.model, "_fused_loop_hint", None) or scene.opt.max_steps),
                        "parallelism": f"{'tile' if tile else 'frame'}-parallel x{world}"},
             # tile-parallel: rank 0 counts its own band's samples; the bands are interleaved, so x world is the frame's

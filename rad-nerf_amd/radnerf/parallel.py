@@ -215,13 +215,24 @@ class FrameParallelRenderer(_Bookkeeping):
             side = self._streams[step % self.n_streams]
             side.wait_event(self._audio_ready)
             with torch.cuda.stream(side):
-                u8 = self._step(step)
-            if self.gather:                                        # collectives are issued from the default stream
-                torch.cuda.current_stream(self.scene.device).wait_stream(side)
+                u8 = self._step(step, flush=False)             # only rendering (and the batch append) happens on the side stream
+            if self.gather and len(self._batch) >= self.gather_every:
+                self._flush_from_default()
             return u8
         return self._step(step)
 
-    def _step(self, step):
+    def _flush_from_default(self):
+        """The collective of a batch whose frames were rendered on side streams: issued on the default stream once EVERY side
+        stream has finished its frames of the batch; the frames were allocated on the side streams, so the caching allocator is
+        told that the default stream (and through it the collective) reads them."""
+        cur = torch.cuda.current_stream(self.scene.device)
+        for st in self._streams:
+            cur.wait_stream(st)
+        for u8 in self._batch:
+            u8.record_stream(cur)
+        self._flush()
+
+    def _step(self, step, flush=True):
         g = frame_of(step, self.rank, self.world)
         if self._audio_batch_ok():
             if self._ab is None or step != self._ab_next or step - self._ab[0] >= self._ab[1].shape[0]:
@@ -229,22 +240,22 @@ class FrameParallelRenderer(_Bookkeeping):
             j = step - self._ab[0]
             self._ab_next = step + 1
             out = self.scene.render(g, want_u8=True, audio_code=(self._ab[1][j:j + 1], self._ab[2][j]))
-            return self._after_render(out)
+            return self._after_render(out, flush)
         self._advance_audio(skipped_frames(step, self.rank, self.world))
         try:
             out = self.scene.render(g, want_u8=True)
         except TypeError:                      # a scene object without the want_u8 option
             out = self.scene.render(g)
-        return self._after_render(out)
+        return self._after_render(out, flush)
 
-    def _after_render(self, out):
+    def _after_render(self, out, flush=True):
         if "image_u8" in out:                  # quantised by the blend kernel itself
             u8 = out["image_u8"].reshape(self.scene.H, self.scene.W, 3)
         else:
             u8 = (out["image"].reshape(self.scene.H, self.scene.W, 3) * 255).to(torch.uint8)
         if self.gather:
             self._batch.append(u8)
-            if len(self._batch) >= self.gather_every:
+            if flush and len(self._batch) >= self.gather_every:
                 self._flush()
         self.last_frame = u8
         self._frames_since_finish += 1
@@ -278,7 +289,10 @@ class FrameParallelRenderer(_Bookkeeping):
         """Wait for every outstanding gather; returns the gathered [world, H, W, 3] uint8 stacks in step order (on rank 0
         only when gather_to == "rank0": the other ranks get an empty list)."""
         if self.gather:
-            self._flush()
+            if self._streams and self._batch:
+                self._flush_from_default()
+            else:
+                self._flush()
         done = []
         for work, buf, _ in self.pending:
             work.wait()
@@ -323,10 +337,18 @@ def stripe_rows(H, rank, world, band=8):
 
 class TileParallelRenderer(_Bookkeeping):
     """BASELINE config 4 (a single 1024^2 frame over 8 GPUs).  `step(i)` renders this rank's rows of global frame i
-    and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (identical on every rank)."""
+    and starts the gather; `finish()` returns the assembled [H, W, 3] uint8 frames (on rank 0; on every rank with gather_to="all")."""
 
-    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule=None, speculate_loop=False):
-        """schedule="verify" (default with the fused engine): band-local step policy, no collective inside the loop, the
+    def __init__(self, scene, rank=0, world=1, dist=None, band=8, schedule=None, speculate_loop=False, gather_to="rank0",
+                 audio_batch=8):
+        """gather_to="rank0" (default): the finished rows go to rank 0 only (the process that shows / encodes the frame) --
+        1/world of the bytes an all_gather moves; finish() then returns the assembled frames on rank 0 and an empty list
+        elsewhere, and the schedule verdicts of schedule="verify" travel back in ONE small broadcast per finish().  "all":
+        every rank assembles every frame (round 2's behaviour).
+        audio_batch = K > 0 (fused engine, resident feature stream): the audio codes, their smoothing recurrence and the bias
+        blocks of the next K frames in four launches instead of four per frame (every rank renders every frame, so the batch is
+        K consecutive global frames).
+        schedule="verify" (default with the fused engine): band-local step policy, no collective inside the loop, the
         schedule checked from counts that ride in the frame's gather, the rare mismatching frame rendered again exactly;
         "frame": every frame with the whole frame's schedule (one 4-byte all-reduce per loop iteration, enqueued on the
         device); "band": band-local policy, never checked (each band is then the reference applied to that band's rays).
@@ -352,6 +374,33 @@ class TileParallelRenderer(_Bookkeeping):
         self.pending = []
         self._static = None     # this rank's slice of the per-pixel inputs that do not change with the frame
         self._rays = {}
+        if gather_to not in ("rank0", "all"):
+            raise ValueError("gather_to must be 'rank0' or 'all'")
+        self.gather_to = gather_to
+        self.audio_batch = max(0, int(audio_batch)) if fused_engine else 0
+        self._ab = None         # (first frame, smoothed codes [K, dim], bias blocks [K, 192])
+
+    def _audio_batch_ok(self):
+        m, sc = self.scene.model, self.scene
+        return (self.audio_batch > 0 and getattr(m, "fused_audio_enabled", None) is not None and m.smooth_lips and sc.opt.att == 2
+                and getattr(sc, "n_frames", 0) >= 8 and sc.aud_features.is_cuda and sc.aud_features.dtype == torch.float32
+                and not m.training and m.fused_audio_enabled())
+
+    def _audio_code(self, i):
+        """(smoothed code [1, dim], bias block [192]) of frame i from a batch computed for frames i0 .. i0 + K - 1, or None
+        (per-frame audio kernels).  Frames must come in order (a stream); a jump starts a new batch from the current state."""
+        if not self._audio_batch_ok():
+            return None
+        from . import audio, fused
+        m, sc = self.scene.model, self.scene
+        if self._ab is None or not (self._ab[0] <= i < self._ab[0] + self._ab[1].shape[0]) or i != self._ab[3]:
+            codes = audio.encode_stream(m, sc.aud_features, i % sc.n_frames, self.audio_batch)
+            states = audio.smooth_seq_(m, codes)
+            code = m.individual_codes[0] if m.individual_dim > 0 else None
+            self._ab = [i, states, fused.frame_bias_batch(m, states, sc.eye, code), i]
+        j = i - self._ab[0]
+        self._ab[3] = i + 1
+        return self._ab[1][j:j + 1], self._ab[2][j]
 
     def _inputs(self, i):
         sc, px = self.scene, self.pix
@@ -368,10 +417,18 @@ class TileParallelRenderer(_Bookkeeping):
         sc = self.scene
         f, (rays_o, rays_d), (bg_coords, bg_color) = self._inputs(i)
         kw = dict(sc.render_kwargs())
+        if audio_code is None:
+            audio_code = self._audio_code(i)
         if audio_code is not None:
             kw["audio_code"] = audio_code
+        fused_engine = getattr(getattr(sc, "opt", None), "engine", "ops") == "fused"
+        if fused_engine:
+            kw["want_u8"] = True                 # quantised by the frame's epilogue kernel, as the frame path does
         out = sc.model.render(rays_o, rays_d, f["auds"], bg_coords, f["poses"], eye=f["eye"], index=f["index"],
                               bg_color=bg_color, **kw)
+        self._last_code = audio_code[0] if audio_code is not None else getattr(sc.model, "enc_a", None)
+        if "image_u8" in out:
+            return out["image_u8"].reshape(-1, sc.W, 3)
         return (out["image"].reshape(-1, sc.W, 3) * 255).to(torch.uint8)
 
     def _render_for_count(self, step):
@@ -379,16 +436,22 @@ class TileParallelRenderer(_Bookkeeping):
 
     _HIST = 17          # live-ray counts entering iterations 0 .. 16 (max_steps = 16 in every BASELINE config)
 
-    def _gather(self, payload):
-        """One collective: every rank's payload (uint8, same length) to every rank.  Returns (work, buf [world, len])."""
+    def _gather(self, payload, to_all=False):
+        """One collective: every rank's payload (uint8, same length) to rank 0 (gather_to="rank0") or to every rank.
+        Returns (work, buf [world, len] or None on the ranks that receive nothing, payload)."""
         nccl = self.dist.get_backend() == "nccl"
         if not nccl:
             payload = payload.cpu()                      # gloo gathers host tensors (CPU tests, 1-GPU rehearsals)
+        payload = payload.contiguous()
+        if self.gather_to == "rank0" and not to_all:
+            buf = torch.empty((self.world, payload.numel()), dtype=torch.uint8, device=payload.device) if self.rank == 0 else None
+            work = self.dist.gather(payload, list(buf.unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
+            return work, buf, payload
         buf = torch.empty((self.world, payload.numel()), dtype=torch.uint8, device=payload.device)
         if nccl:
-            work = self.dist.all_gather_into_tensor(buf, payload.contiguous(), async_op=True)
+            work = self.dist.all_gather_into_tensor(buf, payload, async_op=True)
         else:
-            work = self.dist.all_gather(list(buf.unbind(0)), payload.contiguous(), async_op=True)
+            work = self.dist.all_gather(list(buf.unbind(0)), payload, async_op=True)
         return work, buf, payload
 
     def _payload(self, u8, verify):
@@ -409,7 +472,7 @@ class TileParallelRenderer(_Bookkeeping):
             return u8
         verify = self.schedule == "verify"
         work, buf, sent = self._gather(self._payload(u8, verify))
-        enc_a = getattr(self.scene.model, "enc_a", None)
+        enc_a = getattr(self, "_last_code", None)
         self.pending.append(dict(frame=i, work=work, buf=buf, keep=sent, verify=verify,
                                  enc_a=enc_a.clone() if (verify and torch.is_tensor(enc_a)) else None))
         return u8
@@ -437,25 +500,41 @@ class TileParallelRenderer(_Bookkeeping):
         finally:
             m.shard_schedule = None
         self.redone += 1
-        return self.assemble(self._rows_of(buf))
+        return self.assemble(self._rows_of(buf)) if buf is not None else None
 
     def finish(self):
+        """Wait for the outstanding gathers; returns the assembled frames in step order (gather_to="rank0": on rank 0, an empty
+        list elsewhere)."""
         frames = []
         max_steps = int(getattr(getattr(self.scene, "opt", None), "max_steps", 16))
+        n = self.n_max * self.scene.W * 3
+        n_rays = [len(r) * self.scene.W for r in self.rows]
         for p in self.pending:
+            if p["work"] is not None:
+                p["work"].wait()
+        # schedule verdicts: a rank that holds every band's loop counts (all ranks with gather_to="all", rank 0 otherwise)
+        # decides; with gather_to="rank0" the verdicts of all pending frames go back to the ranks in ONE broadcast
+        bad = []
+        for p in self.pending:
+            ok = True
+            if p["work"] is not None and p.get("verify") and p["buf"] is not None:
+                hist = p["buf"][:, n:n + 4 * self._HIST].cpu().contiguous().view(torch.int32).reshape(self.world, self._HIST).tolist()
+                ok = band_schedule_is_frame_schedule(n_rays, hist, max_steps)
+            bad.append(0 if ok else 1)
+        if self.gather_to == "rank0" and self.dist is not None and self.world > 1 and any(p.get("verify") for p in self.pending):
+            nccl = self.dist.get_backend() == "nccl"
+            flags = torch.tensor(bad, dtype=torch.uint8, device=self.scene.device if nccl else "cpu")
+            self.dist.broadcast(flags, src=0)
+            bad = flags.cpu().tolist()
+        for p, redo in zip(self.pending, bad):
             if p["work"] is None:
                 frames.append(self.assemble(p["keep"][None]))
-                continue
-            p["work"].wait()
-            buf = p["buf"]
-            if p.get("verify"):
-                n = self.n_max * self.scene.W * 3
-                hist = buf[:, n:n + 4 * self._HIST].cpu().contiguous().view(torch.int32).reshape(self.world, self._HIST).tolist()
-                n_rays = [len(r) * self.scene.W for r in self.rows]
-                if not band_schedule_is_frame_schedule(n_rays, hist, max_steps):
-                    frames.append(self._redo_exact(p))           # every rank reaches the same verdict from the same bytes
-                    continue
-            frames.append(self.assemble(self._rows_of(buf)))
+            elif redo:
+                frame = self._redo_exact(p)                  # every rank takes part (it holds an all-reduce per loop iteration)
+                if frame is not None:
+                    frames.append(frame)
+            elif p["buf"] is not None:
+                frames.append(self.assemble(self._rows_of(p["buf"])))
         self.pending = []
         if self.speculate_loop:
             self._update_loop_hint()

@@ -162,14 +162,14 @@ class _TileScene:
         return {}
 
 
-def _tile_worker(rank, world, port, Hh, Ww, band, ret):
+def _tile_worker(rank, world, port, Hh, Ww, band, ret, gather_to="rank0"):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from radnerf.parallel import TileParallelRenderer
-    tpr = TileParallelRenderer(_TileScene(Hh, Ww), rank, world, dist, band=band)
+    tpr = TileParallelRenderer(_TileScene(Hh, Ww), rank, world, dist, band=band, gather_to=gather_to)
     for i in range(2):
         tpr.step(i)
     ret[rank] = [f.numpy() for f in tpr.finish()]
@@ -177,8 +177,9 @@ def _tile_worker(rank, world, port, Hh, Ww, band, ret):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("gather_to", ["rank0", "all"])
 @pytest.mark.parametrize("world,Hh,band", [(2, 16, 4), (3, 20, 4), (2, 10, 8), (8, 128, 8)])   # even / ragged split, short last band, config 4's world of 8
-def test_tile_parallel_equals_whole_frame(hiplib, world, Hh, band):
+def test_tile_parallel_equals_whole_frame(hiplib, world, Hh, band, gather_to):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rad-nerf_amd"))
     from radnerf.parallel import TileParallelRenderer, stripe_rows
@@ -191,8 +192,11 @@ def test_tile_parallel_equals_whole_frame(hiplib, world, Hh, band):
     expect = [f.numpy() for f in whole.finish()]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_tile_worker, args=(world, _free_port(), Hh, Ww, band, ret), nprocs=world, join=True)
+    mp.spawn(_tile_worker, args=(world, _free_port(), Hh, Ww, band, ret, gather_to), nprocs=world, join=True)
     for rank in range(world):
+        if gather_to == "rank0" and rank != 0:
+            assert ret[rank] == []                      # the rows went to rank 0 only
+            continue
         for i in range(2):
             assert np.array_equal(ret[rank][i], expect[i]), (rank, i)
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--schedule", default="verify")
+    ap.add_argument("--gather-to", default="rank0", choices=["rank0", "all"])
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = int(os.environ.get("LOCAL_RANK", "0")) if args.backend == "nccl" else 0
@@ -33,12 +34,14 @@ def main():
     from radnerf.scene import SyntheticScene, default_opt
     size = args.size
     scene = SyntheticScene(H=size, W=size, n_frames=8, device=f"cuda:{dev}", opt=default_opt(engine="fused"))
-    tpr = TileParallelRenderer(scene, rank, world, dist, band=8, schedule=args.schedule)
+    tpr = TileParallelRenderer(scene, rank, world, dist, band=8, schedule=args.schedule, gather_to=args.gather_to)
     with torch.no_grad():
         for i in range(args.frames):
             tpr.step(i)
         frames = [f.cpu() for f in tpr.finish()]
-    print(f"rank {rank}: schedule={tpr.schedule}, frames rendered again with the whole-frame schedule: {tpr.redone}", flush=True)
+    print(f"rank {rank}: backend={dist.get_backend()} world={dist.get_world_size()} schedule={tpr.schedule} gather_to={tpr.gather_to}, "
+          f"frames rendered again with the whole-frame schedule: {tpr.redone}", flush=True)
+    assert (len(frames) == args.frames) if (rank == 0 or args.gather_to == "all") else (frames == [])
     ok = True
     if rank == 0:
         ref = SyntheticScene(H=size, W=size, n_frames=8, device=f"cuda:{dev}", opt=default_opt(engine="fused"))
