@@ -31,7 +31,8 @@ def test_bands_match_oracle_and_reassemble(po, hiplib, engine, world, size):
             m.enc_a = None                      # each real rank owns its model: frame 0 starts without EMA history
             band = tpr.render_local(0)
             f, (rays_o, rays_d), (bg_coords, bg_color) = tpr._inputs(0)
-            img, _, _ = po.render_frame(om, rc, rays_o.cpu().numpy(), rays_d.cpu().numpy(), m.enc_a.cpu().numpy(),
+            code = tpr._last_code          # the frame's smoothed audio code (model.enc_a is the state after the whole audio batch)
+            img, _, _ = po.render_frame(om, rc, rays_o.cpu().numpy(), rays_d.cpu().numpy(), code.cpu().numpy(),
                                         m.individual_codes[0].detach().cpu().numpy(), f["eye"].cpu().numpy(),
                                         bg_coords.cpu().numpy(), f["poses"].cpu().numpy(),
                                         m.individual_codes_torso[0].detach().cpu().numpy(), bg_color.reshape(-1, 3).cpu().numpy())

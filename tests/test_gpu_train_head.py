@@ -74,8 +74,15 @@ def _run(m, xyzs, dirs, enc_a, eye, index, up, mode, monkeypatch):
     return (sigma.detach(), rgb.detach(), amb.detach()), grads
 
 
+@pytest.mark.parametrize("ref_mlp", ["hip", "torch"])
 @pytest.mark.parametrize("grid,M", [("tiledgrid16", 4099), ("hashgrid19", 12345)])
-def test_fused_head_matches_the_operator_path(hiplib, monkeypatch, grid, M):
+def test_fused_head_matches_the_operator_path(hiplib, monkeypatch, grid, M, ref_mlp):
+    """ref_mlp = "torch": the comparison path is the reference's own formulation of the network -- nn.Linear / F.relu / tanh /
+    trunc_exp / sigmoid / cat / repeat under torch.autograd (nerf/network.py:222-283) over the grid and SH operators -- with
+    none of this tree's MLP or glue kernels in it; "hip": the round-2 path (rn_mlp64_* + glue kernels)."""
+    if ref_mlp == "torch":
+        monkeypatch.setenv("RN_MLP_TRAIN", "torch")
+        monkeypatch.setenv("RN_TRAIN_GLUE", "torch")
     kw = dict(xyz_grid="hashgrid", xyz_log2_hashmap_size=19) if grid == "hashgrid19" else {}
     scene = _scene(32, **kw)
     m = scene.model
