@@ -94,6 +94,13 @@ int rn_train_head_loss(const float *image, const float *weights_sum, const float
                        uint32_t N, float *loss, float *pred, float *grad_image, float *grad_weights_sum, float *grad_ambient,
                        rn_stream_t stream);
 
+/* A training batch from a per-pixel table: out = [n, widths[0]] | [n, widths[1]] | ... (each section contiguous), section s
+ * holding columns (widths[0] + .. + widths[s-1]) .. of the rows table[idx[i], :] (idx: int64 device array, row_floats = sum of
+ * the <= 8 widths, given as a HOST array).  One launch where indexing + making each strided column block contiguous takes one
+ * gather and one copy per section (the loader side of nerf/provider.py:588-690 for rays that are already on the device). */
+int rn_train_batch_gather(const float *table, uint32_t row_floats, const int64_t *idx, uint32_t n, const uint32_t *widths,
+                          uint32_t sections, float *out, rn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

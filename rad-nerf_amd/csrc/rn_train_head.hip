@@ -967,6 +967,24 @@ __global__ void __launch_bounds__(kLossThreads) k_train_head_loss(const float *_
     }
 }
 
+// ---- batch gather ---------------------------------------------------------------------------------------------------------
+// A training batch = n rows picked from a per-pixel table [n_px, row_floats] whose columns are up to 8 sections (rays_o | rays_d |
+// bg_coords | bg_color | target | face ...): ONE kernel writes every section as its own contiguous [n, width] array (the
+// operators want contiguous rays), where stock indexing takes one gather + one strided copy per section.
+struct GatherArgs {
+    uint32_t width[8], col0[8], out0[8];   // section widths, first column in the table row, first float in `out`
+    uint32_t sections, row_floats;
+};
+__global__ void __launch_bounds__(256) k_batch_gather(const float *__restrict__ table, const int64_t *__restrict__ idx, uint32_t n,
+                                                      GatherArgs a, float *__restrict__ out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * a.row_floats) return;
+    const uint32_t r = t / a.row_floats, c = t - r * a.row_floats;
+    uint32_t sec = 0;
+    while (sec + 1 < a.sections && c >= a.col0[sec + 1]) sec++;
+    out[a.out0[sec] + r * a.width[sec] + (c - a.col0[sec])] = table[(size_t)idx[r] * a.row_floats + c];
+}
+
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -1103,6 +1121,26 @@ int rn_grid_scatter_lbc(const float *grad, const float *inputs, uint32_t M, cons
     else
         hipLaunchKernelGGL(k_grid_scatter<2>, g, dim3(kScThreads), 0, as_stream(stream), grad, inputs, grid->offsets, grad_table, M, m_dev, lc, grid->gridtype);
     return check_launch("grid_scatter_lbc");
+}
+
+int rn_train_batch_gather(const float *table, uint32_t row_floats, const int64_t *idx, uint32_t n, const uint32_t *widths,
+                          uint32_t sections, float *out, rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    RN_REQUIRE(table && idx && widths && out && sections >= 1 && sections <= 8, "train_batch_gather: null pointer / 1 .. 8 sections");
+    GatherArgs a{};
+    uint32_t col = 0;
+    for (uint32_t i = 0; i < sections; i++) {
+        RN_REQUIRE(widths[i] > 0, "train_batch_gather: section %u has width 0", i);
+        a.width[i] = widths[i];
+        a.col0[i] = col;
+        a.out0[i] = col * n;      // sections follow each other in `out`: [n, w0] | [n, w1] | ...
+        col += widths[i];
+    }
+    RN_REQUIRE(col == row_floats, "train_batch_gather: the section widths must add up to the row length");
+    a.sections = sections;
+    a.row_floats = row_floats;
+    hipLaunchKernelGGL(k_batch_gather, dim3(div_up(n * row_floats, 256)), dim3(256), 0, as_stream(stream), table, idx, n, a, out);
+    return check_launch("train_batch_gather");
 }
 
 int rn_train_head_loss(const float *image, const float *weights_sum, const float *ambient, const float *bg, uint32_t bg_stride,

@@ -275,7 +275,16 @@ class NeRFRenderer(nn.Module):
             if self.training and not isinstance(index, int):
                 # index_select = the same rows as individual_codes[index] (nerf/renderer.py:199); its backward is one index_add
                 # instead of index_put's sort + segmented scatter (5 launches for a one-element index)
-                idx = index if torch.is_tensor(index) else torch.as_tensor(list(index), dtype=torch.long, device=self.individual_codes.device)
+                if torch.is_tensor(index):
+                    idx = index
+                else:       # the loader's Python list: uploaded once per distinct value, not once per step
+                    key = tuple(int(i) for i in index)
+                    cache = self.__dict__.setdefault("_index_cache", {})
+                    idx = cache.get(key)
+                    if idx is None or idx.device != self.individual_codes.device:
+                        if len(cache) > 4096:
+                            cache.clear()
+                        idx = cache[key] = torch.as_tensor(key, dtype=torch.long, device=self.individual_codes.device)
                 ind_code = torch.index_select(self.individual_codes, 0, idx.reshape(-1).long())
             else:
                 ind_code = self.individual_codes[index if self.training else 0]

@@ -228,20 +228,35 @@ class SyntheticTrainStream:
             cols = [f["rays_o"][0], f["rays_d"][0], f["bg_coords"][0], f["bg_color"][0], self.target[0], self.face_mask[0].float().unsqueeze(-1)]
             self._table = torch.cat([c.reshape(n_px, -1).float() for c in cols], dim=1).contiguous()
         idx = torch.randint(0, n_px, (self.n_rays,), device=self.target.device, generator=self.gen)
-        out = self.unpack(self._table.index_select(0, idx))
         import os
+        if self._table.is_cuda and os.environ.get("RN_TRAIN_PACKED", "1") != "0":
+            # one kernel: the picked rows, every column section written as its own contiguous array of one flat buffer
+            from . import train_head
+            flat, _ = train_head.batch_gather(self._table, idx, self._WIDTHS)
+            return self.unpack(flat)
+        rows = self._table.index_select(0, idx)
+        flat = torch.cat([rows[:, a:a + w].reshape(-1) for a, w in zip(self._COL0, self._WIDTHS)])
+        out = self.unpack(flat)
         if os.environ.get("RN_TRAIN_PACKED", "1") == "0":       # experiment switch: separate tensors, as a generic loader would hand over
-            out = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in out.items() if not k.startswith("_")}
+            out = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items() if not k.startswith("_")}
         return out
 
-    def unpack(self, rows):
-        """Batch dict over the columns of `rows` [n_rays, 15]: every per-ray entry is a VIEW (face_mask stays the 0/1 float column),
-        so refreshing `rows` in place refreshes the batch."""
-        v = rows.unsqueeze(0)
+    _WIDTHS = (3, 3, 2, 3, 3, 1)          # rays_o | rays_d | bg_coords | bg_color | target | face: the table's column sections
+    _COL0 = (0, 3, 6, 8, 11, 14)
+
+    def unpack(self, flat):
+        """Batch dict over the sections of `flat` ([n, 3] rays_o | [n, 3] rays_d | [n, 2] bg_coords | [n, 3] bg_color | [n, 3] target |
+        [n] face, each contiguous): every per-ray entry is a VIEW (face_mask stays 0/1 floats), so refreshing `flat` in place
+        refreshes the batch."""
+        n = flat.numel() // sum(self._WIDTHS)
+        sec, at = [], 0
+        for w in self._WIDTHS:
+            sec.append(flat[at:at + n * w].view(1, n, w))
+            at += n * w
         f = self.f
-        return dict(rays_o=v[..., 0:3], rays_d=v[..., 3:6], bg_coords=v[..., 6:8], poses=f["poses"], face_mask=v[..., 14],
-                    eye=f["eye"], auds=f["auds"], index=[self.frame], bg_color=v[..., 8:11], images=v[..., 11:14],
-                    bg_torso_color=v[..., 11:14], _packed=rows, _unpack=self.unpack)
+        return dict(rays_o=sec[0], rays_d=sec[1], bg_coords=sec[2], poses=f["poses"], face_mask=sec[5].view(1, n),
+                    eye=f["eye"], auds=f["auds"], index=[self.frame], bg_color=sec[3], images=sec[4],
+                    bg_torso_color=sec[4], _packed=flat, _unpack=self.unpack)
 
 
 class Trainer:

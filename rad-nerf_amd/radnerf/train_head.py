@@ -33,6 +33,7 @@ _SIGS = {
     "rn_train_head_weight_grads": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _u32, _ptr, _ptr, C.POINTER(HeadGradsT), _ptr, _ptr],
     "rn_grid_scatter_lbc": [_ptr, _ptr, _u32, _ptr, C.POINTER(GridT), _ptr, _ptr],
     "rn_train_head_loss": [_ptr, _ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _u32, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_train_batch_gather": [_ptr, _u32, _ptr, _u32, C.POINTER(_u32), _u32, _ptr, _ptr],
 }
 for _n, _a in _SIGS.items():
     getattr(_lib, _n).argtypes = _a
@@ -85,8 +86,11 @@ class _HeadTrain(torch.autograd.Function):
         image = torch.empty(int(_lib.rn_train_head_image_floats()), dtype=torch.float32, device=dev)
         hip.call("rn_train_head_pack", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), hip.ptr(image), s)
         work = torch.empty(int(_lib.rn_train_head_workspace_floats(M)), dtype=torch.float32, device=dev)
-        # one block for the outputs: rows past the live count are never written by the kernel and must read as zero
-        out = torch.zeros(M, 12, dtype=torch.float32, device=dev) if m_dev is not None else torch.empty(M, 12, dtype=torch.float32, device=dev)
+        # one block for the outputs.  Rows past the live count are not written: they belong to no ray, so the compositor never
+        # reads them and the backward kernel skips them (RN_TRAIN_HEAD_ZERO=1 zero-fills the block, for tools that look at all rows)
+        import os
+        out = (torch.zeros if (m_dev is not None and os.environ.get("RN_TRAIN_HEAD_ZERO") == "1") else torch.empty)(
+            M, 12, dtype=torch.float32, device=dev)
         flat = out.view(-1)
         sigmas, amb_abs = flat[0:M], flat[M:2 * M]
         rgbs, ambient = flat[2 * M:5 * M].view(M, 3), flat[5 * M:7 * M].view(M, 2)
@@ -218,3 +222,22 @@ def head_loss(image, weights_sum, ambient, bg, target, face, w_amb):
             t = t.contiguous()
         return t
     return _HeadLoss.apply(image, weights_sum, ambient, rows(bg, 3), rows(target, 3), rows(face, 1), w_amb.reshape(1))
+
+
+def batch_gather(table, idx, widths):
+    """[n, w0] | [n, w1] | ... = the column sections of table[idx] ([n_px, sum(widths)] fp32, idx int64), each contiguous, as views
+    of ONE flat buffer; returns (flat, [section views])."""
+    n, row = idx.shape[0], table.shape[1]
+    assert sum(widths) == row and table.is_contiguous() and table.dtype == torch.float32 and idx.dtype == torch.int64
+    flat = torch.empty(n * row, dtype=torch.float32, device=table.device)
+    w = (_u32 * len(widths))(*widths)
+    hip.call("rn_train_batch_gather", hip.ptr(table), row, hip.ptr(idx), n, w, len(widths), hip.ptr(flat), hip.stream())
+    return flat, split_sections(flat, n, widths)
+
+
+def split_sections(flat, n, widths):
+    out, at = [], 0
+    for wd in widths:
+        out.append(flat[at:at + n * wd].view(n, wd))
+        at += n * wd
+    return out

@@ -246,9 +246,9 @@ class _composite_rays_train(Function):
         # grad_depth is ignored, as in the reference (raymarching.py:324)
         sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image = ctx.saved_tensors
         M, N, T_thresh = ctx.dims
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
-        grad_ambient = torch.zeros_like(ambient)
+        # zero-initialised: samples that belong to no ray (rows past the counter) receive no gradient -- one memset for the three
+        flat = torch.zeros(M * 5, dtype=_f32, device=sigmas.device)
+        grad_sigmas, grad_ambient, grad_rgbs = flat[:M], flat[M:2 * M], flat[2 * M:].view(M, 3)
         grad_weights_sum, grad_ambient_sum = grad_weights_sum.contiguous(), grad_ambient_sum.contiguous()
         grad_image = grad_image.contiguous()
         hip.call("rn_composite_rays_train_backward", hip.ptr(grad_weights_sum, _f32),

@@ -118,9 +118,10 @@ def test_fused_head_matches_the_operator_path(hiplib, monkeypatch, grid, M, ref_
         assert err < 2e-3 and cos > 0.99999, (name, err, cos)
 
 
-def test_fused_head_live_count_bounds_the_rows(hiplib):
+def test_fused_head_live_count_bounds_the_rows(hiplib, monkeypatch):
     """Rows past the device-side live count get no output and contribute no gradient (the zero rows behind the marcher's
     counter, raymarching/raymarching.py:231-257)."""
+    monkeypatch.setenv("RN_TRAIN_HEAD_ZERO", "1")          # zero-filled output block, so that the untouched rows can be told
     scene = _scene(32)
     m = scene.model
     m.train()
@@ -255,4 +256,18 @@ def test_training_step_launch_count(hiplib, monkeypatch):
     kernels = [e for e in prof.events() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
     names = [e.name for e in kernels]
     print(len(names), "device activities:", sorted(set(names)))
-    assert 0 < len(names) <= 48, names
+    assert 0 < len(names) <= 40, names
+
+
+def test_batch_gather_equals_indexing(hiplib):
+    from radnerf import train_head
+    g = torch.Generator(device="cuda").manual_seed(9)
+    table = torch.rand(5000, 15, device="cuda", generator=g)
+    idx = torch.randint(0, 5000, (4096,), device="cuda", generator=g)
+    widths = (3, 3, 2, 3, 3, 1)
+    flat, secs = train_head.batch_gather(table, idx, widths)
+    rows, at = table[idx], 0
+    for sec, w in zip(secs, widths):
+        assert sec.is_contiguous() and torch.equal(sec, rows[:, at:at + w])
+        at += w
+    assert flat.numel() == 4096 * 15
