@@ -84,6 +84,32 @@ int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, c
 int rn_grid_scatter_lbc(const float *grad, const float *inputs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid,
                         float *grad_table, rn_stream_t stream);
 
+/* The same gradient with the large levels summed by TABLE REGION instead of by workgroup (two launches).  A level with at least
+ * 16 buckets of 4096 rows that is HASHED is "binned": the first kernel appends its (row, w g) entries to the bucket that
+ * owns the row, the second has one workgroup per bucket add them in LDS and update the region with plain loads and stores -- no
+ * global float atomic on those levels (the hashed levels of a T = 2^19 table are touched ~5 times per launch, but never twice by
+ * one workgroup, so a per-workgroup merge leaves one memory-side request per corner pair there).  The other levels go through
+ * the LDS line merge of rn_grid_scatter_lbc inside the same first launch.  offsets_host: host copy of grid->offsets [L + 1];
+ * workspace: rn_grid_scatter_workspace() bytes, 256-byte aligned, ZEROED once by the caller before first use (bucket cursors
+ * live at its start and are left zero by every call).  Same results up to summation order.  The rows of a BINNED level are
+ * WRITTEN (each by the one workgroup that owns its region), not accumulated: the caller need not zero them, and must not
+ * expect earlier contents to survive; rows of the other levels are accumulated into (zero them first). */
+size_t rn_grid_scatter_workspace(uint32_t M, const rn_grid_t *grid, const int32_t *offsets_host);
+/* Bit l set: level l of this grid is binned (its rows of grad_table are written, not accumulated into). */
+uint32_t rn_grid_scatter_binned_levels(const rn_grid_t *grid, const int32_t *offsets_host);
+/* One or two grids at once -- what the training step calls for its xyz and ambient grids: the line-merged levels of both grids
+ * share ONE launch, job 0's binned levels (offsets_host + workspace given) take the two bucket launches.  3 launches in all. */
+typedef struct {
+    const float *grad, *inputs;      /* [L, M, 2] level-major feature gradients, [M, D] normalised coordinates */
+    const rn_grid_t *grid;
+    const int32_t *offsets_host;     /* host copy of grid->offsets (job 0, nullable: no binning) */
+    float *grad_table;
+} rn_scatter_job_t;
+int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t M, const int32_t *m_dev, void *workspace,
+                         size_t workspace_bytes, rn_stream_t stream);
+int rn_grid_scatter_binned(const float *grad, const float *inputs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid,
+                           const int32_t *offsets_host, float *grad_table, void *workspace, size_t workspace_bytes, rn_stream_t stream);
+
 /* Head loss of the training step on the composited rays (nerf/renderer.py:306 + nerf/utils.py:772-803):
  *   pred = clamp(image + (1 - weights_sum) * bg, 0, 1);
  *   loss = mean_n mean_c (pred - target)^2 + 1e-4 mean_n H(clamp(ws, 1e-5, 1 - 1e-5)) + *w_amb mean_n (ambient_n (1 - face_n))

@@ -834,39 +834,43 @@ __device__ __forceinline__ bool merge_runs4(uint32_t key, uint32_t key2, float (
     return tail && key != kScEmpty;
 }
 
+// One level of one chunk of samples through the LDS line merge (the non-binned levels).
+struct ScatterJob {
+    const float *grad, *inputs;
+    const int32_t *offsets;
+    float *grad_grid;
+    LevelConsts lc;
+    uint32_t gridtype, n_levels;
+    uint32_t level_of[kMaxLevels];    // the levels this job covers (blockIdx.y indexes this list)
+};
+
 template <uint32_t D>
-__global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__restrict__ grad, const float *__restrict__ inputs,
-                                                             const int32_t *__restrict__ offsets, float *__restrict__ grad_grid,
-                                                             uint32_t Mcap, const int32_t *__restrict__ m_dev, LevelConsts lc,
-                                                             uint32_t gridtype) {
+__device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap, uint32_t M, uint32_t *keys, float *vals) {
     constexpr uint32_t P = 1u << (D - 1);            // x-pairs of corners per sample
     constexpr uint32_t kScSamples = kScThreads / P;  // lanes 0 .. S-1: pair 0 of the S samples, lanes S .. 2S-1: pair 1, ...
-    __shared__ uint32_t keys[kScSlots];
-    __shared__ __attribute__((aligned(16))) float vals[kScSlots * 16];
-    const uint32_t M = live_count(Mcap, m_dev);
-    if (blockIdx.x * kScSamples >= M) return;
+    if (blockIdx.y >= j.n_levels || blockIdx.x * kScSamples >= M) return;
+    const uint32_t level = j.level_of[blockIdx.y];
     for (uint32_t i = threadIdx.x; i < kScSlots; i += kScThreads) keys[i] = kScEmpty;
     for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) vals[i] = 0.0f;
     __syncthreads();
-    const uint32_t level = blockIdx.y;
-    const uint32_t off = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-    float *gg = grad_grid + (size_t)off * 2;
+    const uint32_t off = (uint32_t)j.offsets[level];
+    const uint32_t hashmap_size = (uint32_t)j.offsets[level + 1] - off;
+    float *gg = j.grad_grid + (size_t)off * 2;
     const uint32_t b = blockIdx.x * kScSamples + (threadIdx.x & (kScSamples - 1u));
     const uint32_t q = threadIdx.x / kScSamples;      // this thread's x-pair: bits of q = the y (, z) corner
     float in[D];
     bool live = b < M;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        in[d] = live ? inputs[(size_t)b * D + d] : 0.0f;
+        in[d] = live ? j.inputs[(size_t)b * D + d] : 0.0f;
         live = live && !(in[d] < 0 || in[d] > 1);     // gridencoder.cu:275-280
     }
     float pos[D], pos_deriv[D];
     uint32_t pos_grid[D];
-    lattice_pos<D>(in, lc.scale[level], false, 0, pos, pos_deriv, pos_grid);
+    lattice_pos<D>(in, j.lc.scale[level], false, 0, pos, pos_deriv, pos_grid);
     float2 g = make_float2(0.0f, 0.0f);
-    if (live) g = *reinterpret_cast<const float2 *>(grad + ((size_t)level * Mcap + b) * 2);
-    const uint32_t resolution = lc.resolution[level];
+    if (live) g = *reinterpret_cast<const float2 *>(j.grad + ((size_t)level * Mcap + b) * 2);
+    const uint32_t resolution = j.lc.resolution[level];
     {
         uint32_t pgl[D];
         pgl[0] = pos_grid[0];
@@ -881,9 +885,9 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__rest
         }
         uint32_t row0 = kScEmpty, row1 = kScEmpty;
         if (live) {
-            row0 = grid_row<D>(gridtype, false, hashmap_size, resolution, pgl);
+            row0 = grid_row<D>(j.gridtype, false, hashmap_size, resolution, pgl);
             pgl[0] += 1u;
-            row1 = grid_row<D>(gridtype, false, hashmap_size, resolution, pgl);
+            row1 = grid_row<D>(j.gridtype, false, hashmap_size, resolution, pgl);
         }
         float v[4] = {wyz[0] * g.x, wyz[0] * g.y, wyz[1] * g.x, wyz[1] * g.y};
         if (merge_runs4(row0, row1, v)) {
@@ -915,6 +919,183 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(const float *__rest
         if (line != kScEmpty) {
             const float v = vals[i];
             if (v != 0.0f) atomicAdd(gg + (size_t)line * 16 + (i & 15u), v);
+        }
+    }
+}
+
+// One launch for the line-merged levels of up to two grids (blockIdx.z = job: the 3-D grid's non-binned levels and the 2-D grid)
+template <uint32_t D0, uint32_t D1>
+__global__ void __launch_bounds__(kScThreads) k_grid_scatter(ScatterJob j0, ScatterJob j1, uint32_t Mcap, const int32_t *__restrict__ m_dev) {
+    __shared__ uint32_t keys[kScSlots];
+    __shared__ __attribute__((aligned(16))) float vals[kScSlots * 16];
+    const uint32_t M = live_count(Mcap, m_dev);
+    if (blockIdx.z == 0) scatter_lines<D0>(j0, Mcap, M, keys, vals);
+    else scatter_lines<D1>(j1, Mcap, M, keys, vals);
+}
+
+// Binned levels.  A level whose gradient table is much larger than what one workgroup's samples touch (the hashed levels of the
+// T = 2^19 table: 65 536 lines each, touched ~5 times per launch, never twice by the same workgroup) gains nothing from a
+// per-workgroup merge: every (sample, corner) is a memory-side atomic request of its own line.  Those levels are summed by TABLE
+// REGION instead: pass A (k_grid_bin) appends (row, w g0, w g1) entries to the bucket that owns the row -- a bucket = 2^shift
+// consecutive rows of one level -- and pass B (k_grid_scatter_buckets) has one workgroup per bucket add the bucket's entries in
+// LDS and update the region with plain coalesced loads and stores: no global float atomic at all on those levels.  A workgroup
+// of pass A reserves room in the buckets with one returning atomic per bucket (LDS histogram of its 256 samples x 2^D corners).
+constexpr uint32_t kMaxBucketsPerLevel = 128;
+struct BinPlan {
+    uint32_t n_levels, level_of[kMaxLevels];   // the binned levels
+    uint32_t bucket0[kMaxLevels];     // first bucket of level_of[i]
+    uint32_t n_buckets[kMaxLevels];
+    uint32_t shift, cap;              // rows per bucket = 1 << shift; entries a bucket has room for
+    uint32_t *cursor;                 // [total buckets] entries appended (zero before pass A; pass B leaves it zero)
+    uint32_t *e_row;                  // [total buckets][cap] level-local row
+    float2 *e_val;                    // [total buckets][cap]
+    // Entries that find their bucket full go to ONE spill list with room for every entry of a launch (it cannot overflow); each
+    // pass-B workgroup picks its own out of it.  Hashed rows load the buckets evenly, so the list stays empty unless many samples
+    // coincide -- correctness does not depend on the bucket size, only speed does.
+    uint32_t *spill_count;            // [2]: entries spilled | pass-B workgroups that have read it (the last one resets both)
+    uint32_t *spill_key;              // [spill capacity] bucket << 16 | bucket-local row (rows per bucket <= 2^13)
+    float2 *spill_val;
+};
+constexpr uint32_t kBinThreads = 256;
+
+template <uint32_t D>
+__global__ void __launch_bounds__(kBinThreads) k_grid_bin(ScatterJob j, uint32_t Mcap, const int32_t *__restrict__ m_dev, BinPlan bp) {
+    constexpr uint32_t NC = 1u << D;
+    __shared__ uint32_t hist[kMaxBucketsPerLevel], base[kMaxBucketsPerLevel];
+    const uint32_t M = live_count(Mcap, m_dev);
+    if (blockIdx.x * kBinThreads >= M) return;
+    const uint32_t li = blockIdx.y, level = bp.level_of[li];
+    if (threadIdx.x < kMaxBucketsPerLevel) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t off = (uint32_t)j.offsets[level];
+    const uint32_t hashmap_size = (uint32_t)j.offsets[level + 1] - off;
+    const uint32_t b = blockIdx.x * kBinThreads + threadIdx.x;      // one sample per thread, all 2^D corners
+    float in[D];
+    bool live = b < M;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = live ? j.inputs[(size_t)b * D + d] : 0.0f;
+        live = live && !(in[d] < 0 || in[d] > 1);
+    }
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+    lattice_pos<D>(in, j.lc.scale[level], false, 0, pos, pos_deriv, pos_grid);
+    float2 g = make_float2(0.0f, 0.0f);
+    if (live) g = *reinterpret_cast<const float2 *>(j.grad + ((size_t)level * Mcap + b) * 2);
+    const uint32_t resolution = j.lc.resolution[level];
+    uint32_t rows[NC], rank[NC];
+    float w[NC];
+#pragma unroll
+    for (uint32_t idx = 0; idx < NC; idx++) {
+        float wt = 1;                                 // gridencoder.cu:298-308: x term first
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const bool hi = (idx >> d) & 1u;
+            wt *= hi ? pos[d] : 1 - pos[d];
+            pgl[d] = pos_grid[d] + (hi ? 1u : 0u);
+        }
+        w[idx] = wt;
+        rows[idx] = live ? grid_row<D>(j.gridtype, false, hashmap_size, resolution, pgl) : 0u;
+        rank[idx] = live ? atomicAdd(&hist[rows[idx] >> bp.shift], 1u) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < bp.n_buckets[li]) {
+        const uint32_t n = hist[threadIdx.x];
+        base[threadIdx.x] = n ? atomicAdd(&bp.cursor[bp.bucket0[li] + threadIdx.x], n) : 0u;
+    }
+    __syncthreads();
+    if (!live) return;
+    uint32_t full = 0;                                  // corners whose bucket had no room left (normally none)
+#pragma unroll
+    for (uint32_t idx = 0; idx < NC; idx++) {
+        const uint32_t b_ = rows[idx] >> bp.shift, at = base[b_] + rank[idx];
+        if (at < bp.cap) {
+            const size_t slot = (size_t)(bp.bucket0[li] + b_) * bp.cap + at;
+            bp.e_row[slot] = rows[idx];
+            bp.e_val[slot] = make_float2(w[idx] * g.x, w[idx] * g.y);
+        } else {
+            full |= 1u << idx;
+        }
+    }
+    if (full) {                                         // the spill list (sized for every entry of the launch)
+#pragma unroll
+        for (uint32_t idx = 0; idx < NC; idx++) {
+            if (full & (1u << idx)) {
+                const uint32_t sp = atomicAdd(&bp.spill_count[0], 1u);
+                bp.spill_key[sp] = ((bp.bucket0[li] + (rows[idx] >> bp.shift)) << 16) | (rows[idx] & ((1u << bp.shift) - 1u));
+                bp.spill_val[sp] = make_float2(w[idx] * g.x, w[idx] * g.y);
+            }
+        }
+    }
+}
+
+// Pass B: one workgroup per bucket.  acc[rows of the bucket][2] in LDS (32 KB for 4096 rows), the bucket's entries (and its share
+// of the spill list, normally empty) added with LDS atomics from all lanes, then the region WRITTEN with plain 16-byte stores:
+// every row of a binned level is written by exactly one workgroup, so those levels need neither a memset nor a global atomic.
+constexpr uint32_t kBkThreads = 512;
+__global__ void __launch_bounds__(kBkThreads) k_grid_scatter_buckets(const int32_t *__restrict__ offsets, float *__restrict__ grad_grid,
+                                                                     BinPlan bp, uint32_t total_buckets) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    __shared__ uint32_t n_sh, spill_sh;
+    const uint32_t b = blockIdx.x;
+    if (b >= total_buckets) return;
+    uint32_t li = 0;
+    for (uint32_t i = 0; i < bp.n_levels; i++)
+        if (b >= bp.bucket0[i] && b < bp.bucket0[i] + bp.n_buckets[i]) li = i;
+    const uint32_t level = bp.level_of[li];
+    const uint32_t rows_pb = 1u << bp.shift, local = b - bp.bucket0[li];
+    const uint32_t off = (uint32_t)offsets[level], rows_level = (uint32_t)offsets[level + 1] - off;
+    const uint32_t row_first = local << bp.shift;
+    const uint32_t n_rows = rows_level - row_first < rows_pb ? rows_level - row_first : rows_pb;
+    if (threadIdx.x == 0) {
+        const uint32_t n = bp.cursor[b];
+        n_sh = n < bp.cap ? n : bp.cap;
+        bp.cursor[b] = 0u;                     // ready for the next launch of pass A
+        spill_sh = __hip_atomic_load(&bp.spill_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (uint32_t i = threadIdx.x; i < rows_pb * 2; i += kBkThreads) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t n = n_sh, n_spill = spill_sh;
+    const uint32_t *er = bp.e_row + (size_t)b * bp.cap;
+    const float2 *ev = bp.e_val + (size_t)b * bp.cap;
+    // eight entries per thread in flight: the loads of a batch are issued together, then added (a load-add-load-add chain would
+    // pay the memory latency once per entry)
+    for (uint32_t i0 = 0; i0 < n; i0 += kBkThreads * 8) {
+        uint32_t r[8];
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * kBkThreads + threadIdx.x;
+            const uint32_t ic = i < n ? i : n - 1u;
+            r[u] = er[ic] & (rows_pb - 1u);
+            v[u] = ev[ic];
+            if (i >= n) v[u] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (v[u].x != 0.0f) atomicAdd(&acc[2 * r[u]], v[u].x);
+            if (v[u].y != 0.0f) atomicAdd(&acc[2 * r[u] + 1], v[u].y);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n_spill; i += kBkThreads) {     // normally n_spill == 0
+        const uint32_t key = bp.spill_key[i];
+        if ((key >> 16) == b) {
+            const float2 v = bp.spill_val[i];
+            atomicAdd(&acc[2 * (key & 0xffffu)], v.x);
+            atomicAdd(&acc[2 * (key & 0xffffu) + 1], v.y);
+        }
+    }
+    __syncthreads();
+    float4 *dst = reinterpret_cast<float4 *>(grad_grid + ((size_t)off + row_first) * 2);   // rows are 8 B, regions start on 64-B lines
+    const float4 *src = reinterpret_cast<const float4 *>(acc);
+    for (uint32_t i = threadIdx.x; i < n_rows / 2; i += kBkThreads) dst[i] = src[i];
+    // the last workgroup to have read the spill list empties it for the next launch
+    if (threadIdx.x == 0) {
+        const uint32_t done = atomicAdd(&bp.spill_count[1], 1u) + 1u;
+        if (done == total_buckets) {
+            __hip_atomic_store(&bp.spill_count[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bp.spill_count[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1108,19 +1289,168 @@ int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, c
     return check_launch("train_head_weight_grads");
 }
 
+}  // extern "C"
+
+namespace rn {
+namespace th {
+
+// Which levels are binned: the HASHED ones with at least kMinBuckets buckets of 2^shift rows.  A hash spreads the rows evenly
+// over the buckets whatever the samples' positions, so a bucket's load is known in advance (2x the mean + slack is never
+// reached) and pass B has hundreds of equal workgroups.  Dense and tiled levels keep the per-workgroup line merge: their rows
+// follow the samples' positions (the ambient coordinates of a call cluster in a few cells), which is where neighbouring samples
+// share lines and where a fixed bucket size would overflow.
+constexpr uint32_t kMinBuckets = 16;
+static uint32_t bucket_shift() {
+    static uint32_t sh = 0;
+    if (!sh) {
+        const char *e = getenv("RN_SCATTER_BUCKET_SHIFT");
+        const long v = e ? atol(e) : 12;           // 4096 rows = 32 KB of LDS per bucket: four pass-B workgroups per CU
+        sh = (uint32_t)(v < 10 ? 10 : (v > 13 ? 13 : v));
+    }
+    return sh;
+}
+static uint32_t plan_bins(const rn_grid_t *grid, const int32_t *offsets_host, uint32_t M, BinPlan &bp, bool *binned /* [L] */) {
+    bp = BinPlan{};
+    bp.shift = bucket_shift();
+    const LevelConsts lc = make_level_consts(grid->L, grid->S, grid->H);
+    uint32_t total = 0, min_b = kMaxBucketsPerLevel;
+    for (uint32_t l = 0; l < grid->L; l++) {
+        const uint32_t rows = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        uint64_t stride = 1;                                      // gridencoder.cu:66-84: hashed when the dense index does not fit
+        for (uint32_t d = 0; d < grid->D; d++)
+            if (stride <= rows) stride *= (uint64_t)lc.resolution[l] + 1u;
+        const bool hashed = grid->gridtype == 0 && stride > rows;
+        const uint32_t nb = (rows + (1u << bp.shift) - 1u) >> bp.shift;
+        const bool bin = hashed && nb >= kMinBuckets && nb <= kMaxBucketsPerLevel;
+        if (binned) binned[l] = bin;
+        if (bin) {
+            bp.level_of[bp.n_levels] = l;
+            bp.bucket0[bp.n_levels] = total;
+            bp.n_buckets[bp.n_levels] = nb;
+            bp.n_levels++;
+            total += nb;
+            if (nb < min_b) min_b = nb;
+        }
+    }
+    bp.cap = total ? (uint32_t)(2u * (((uint64_t)M << grid->D) / min_b) + 2048u) : 0u;   // 2 x the mean load of a bucket + slack
+    return total;
+}
+static ScatterJob make_job(const rn_scatter_job_t &j) {
+    ScatterJob s{};
+    s.grad = j.grad;
+    s.inputs = j.inputs;
+    s.offsets = j.grid->offsets;
+    s.grad_grid = j.grad_table;
+    s.lc = make_level_consts(j.grid->L, j.grid->S, j.grid->H);
+    s.gridtype = j.grid->gridtype;
+    return s;
+}
+template <uint32_t D0>
+static void launch_lines(uint32_t D1, dim3 g, hipStream_t s, const ScatterJob &a, const ScatterJob &b, uint32_t M, const int32_t *m_dev) {
+    if (D1 == 3) hipLaunchKernelGGL((k_grid_scatter<D0, 3>), g, dim3(kScThreads), 0, s, a, b, M, m_dev);
+    else hipLaunchKernelGGL((k_grid_scatter<D0, 2>), g, dim3(kScThreads), 0, s, a, b, M, m_dev);
+}
+
+}  // namespace th
+}  // namespace rn
+
+using namespace rn;
+using namespace rn::th;
+
+extern "C" {
+
+size_t rn_grid_scatter_workspace(uint32_t M, const rn_grid_t *grid, const int32_t *offsets_host) {
+    if (!grid || !offsets_host || grid->L > kMaxLevels) return 0;
+    BinPlan bp;
+    const uint32_t total = plan_bins(grid, offsets_host, M, bp, nullptr);
+    if (!total) return 256;
+    const size_t spill = ((size_t)M << grid->D) * bp.n_levels;        // every entry of a launch fits the spill list
+    return (((size_t)(total + 2) * sizeof(uint32_t) + 255u) & ~(size_t)255u) + ((size_t)total * bp.cap + spill) * (sizeof(uint32_t) + sizeof(float2)) + 256;
+}
+
+uint32_t rn_grid_scatter_binned_levels(const rn_grid_t *grid, const int32_t *offsets_host) {
+    if (!grid || !offsets_host || grid->L > kMaxLevels) return 0;
+    BinPlan bp;
+    bool binned[kMaxLevels] = {};
+    (void)plan_bins(grid, offsets_host, 1, bp, binned);
+    uint32_t mask = 0;
+    for (uint32_t l = 0; l < grid->L; l++) mask |= binned[l] ? (1u << l) : 0u;
+    return mask;
+}
+
+int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t M, const int32_t *m_dev, void *workspace,
+                         size_t workspace_bytes, rn_stream_t stream) {
+    if (M == 0) return RN_OK;
+    RN_REQUIRE(jobs && (n_jobs == 1 || n_jobs == 2), "grid_scatter_jobs: one or two jobs");
+    for (uint32_t i = 0; i < n_jobs; i++) {
+        const rn_scatter_job_t &j = jobs[i];
+        RN_REQUIRE(j.grad && j.inputs && j.grid && j.grid->offsets && j.grad_table, "grid_scatter_jobs: null pointer in job %u", i);
+        RN_REQUIRE((j.grid->D == 2 || j.grid->D == 3) && j.grid->L >= 1 && j.grid->L <= kMaxLevels, "grid_scatter_jobs: D must be 2 or 3, L <= 32");
+        RN_REQUIRE(((uintptr_t)j.grad_table & 63u) == 0 && ((uintptr_t)j.grad & 7u) == 0, "grid_scatter_jobs: grad_table must be 64-byte, grad 8-byte aligned");
+    }
+    hipStream_t s = as_stream(stream);
+    ScatterJob sj[2] = {make_job(jobs[0]), n_jobs == 2 ? make_job(jobs[1]) : ScatterJob{}};
+    // job 0 may have binned levels (needs the host copy of its offsets and the workspace)
+    bool binned[kMaxLevels] = {};
+    BinPlan bp{};
+    uint32_t total = 0;
+    if (jobs[0].offsets_host && workspace) {
+        total = plan_bins(jobs[0].grid, jobs[0].offsets_host, M, bp, binned);
+        if (total) {
+            RN_REQUIRE(((uintptr_t)workspace & 255u) == 0 && workspace_bytes >= rn_grid_scatter_workspace(M, jobs[0].grid, jobs[0].offsets_host),
+                       "grid_scatter_jobs: workspace too small / not 256-byte aligned");
+            // workspace = cursors (zeroed once by the caller; pass B leaves them zero) | values | rows
+            char *w = static_cast<char *>(workspace);
+            const size_t spill = ((size_t)M << jobs[0].grid->D) * bp.n_levels;
+            bp.cursor = reinterpret_cast<uint32_t *>(w);
+            bp.spill_count = bp.cursor + total;
+            size_t at = ((size_t)(total + 2) * sizeof(uint32_t) + 255u) & ~(size_t)255u;
+            bp.e_val = reinterpret_cast<float2 *>(w + at);
+            at += (size_t)total * bp.cap * sizeof(float2);
+            bp.spill_val = reinterpret_cast<float2 *>(w + at);
+            at += spill * sizeof(float2);
+            bp.e_row = reinterpret_cast<uint32_t *>(w + at);
+            at += (size_t)total * bp.cap * sizeof(uint32_t);
+            bp.spill_key = reinterpret_cast<uint32_t *>(w + at);
+        }
+    }
+    uint32_t max_levels = 0, max_blocks = 0;
+    for (uint32_t i = 0; i < n_jobs; i++) {
+        for (uint32_t l = 0; l < jobs[i].grid->L; l++)
+            if (!(i == 0 && total && binned[l])) sj[i].level_of[sj[i].n_levels++] = l;
+        if (sj[i].n_levels > max_levels) max_levels = sj[i].n_levels;
+        const uint32_t blocks = div_up(M, kScThreads >> (jobs[i].grid->D - 1));
+        if (blocks > max_blocks) max_blocks = blocks;
+    }
+    if (total) {
+        const dim3 gb(div_up(M, kBinThreads), bp.n_levels);
+        if (jobs[0].grid->D == 3) hipLaunchKernelGGL(k_grid_bin<3>, gb, dim3(kBinThreads), 0, s, sj[0], M, m_dev, bp);
+        else hipLaunchKernelGGL(k_grid_bin<2>, gb, dim3(kBinThreads), 0, s, sj[0], M, m_dev, bp);
+        const size_t shm = (size_t)2 * sizeof(float) << bp.shift;
+        if (shm > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grid_scatter_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(k_grid_scatter_buckets, dim3(total), dim3(kBkThreads), shm, s, jobs[0].grid->offsets, jobs[0].grad_table, bp, total);
+    }
+    if (max_levels) {
+        const dim3 g(max_blocks, max_levels, n_jobs);
+        const uint32_t D1 = n_jobs == 2 ? jobs[1].grid->D : 2u;
+        if (jobs[0].grid->D == 3) launch_lines<3>(D1, g, s, sj[0], sj[1], M, m_dev);
+        else launch_lines<2>(D1, g, s, sj[0], sj[1], M, m_dev);
+    }
+    return check_launch("grid_scatter_jobs");
+}
+
+int rn_grid_scatter_binned(const float *grad, const float *inputs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid,
+                           const int32_t *offsets_host, float *grad_table, void *workspace, size_t workspace_bytes, rn_stream_t stream) {
+    RN_REQUIRE(offsets_host && workspace, "grid_scatter_binned: null pointer");
+    const rn_scatter_job_t j{grad, inputs, grid, offsets_host, grad_table};
+    return rn_grid_scatter_jobs(&j, 1, M, m_dev, workspace, workspace_bytes, stream);
+}
+
 int rn_grid_scatter_lbc(const float *grad, const float *inputs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid,
                         float *grad_table, rn_stream_t stream) {
-    if (M == 0) return RN_OK;
-    RN_REQUIRE(grad && inputs && grid && grid->embeddings == grid->embeddings && grid->offsets && grad_table, "grid_scatter_lbc: null pointer");
-    RN_REQUIRE((grid->D == 2 || grid->D == 3) && grid->L >= 1 && grid->L <= kMaxLevels, "grid_scatter_lbc: D must be 2 or 3, L <= 32");
-    RN_REQUIRE(((uintptr_t)grad_table & 63u) == 0 && ((uintptr_t)grad & 7u) == 0, "grid_scatter_lbc: grad_table must be 64-byte, grad 8-byte aligned");
-    const LevelConsts lc = make_level_consts(grid->L, grid->S, grid->H);
-    const dim3 g(div_up(M, kScThreads >> (grid->D - 1)), grid->L);
-    if (grid->D == 3)
-        hipLaunchKernelGGL(k_grid_scatter<3>, g, dim3(kScThreads), 0, as_stream(stream), grad, inputs, grid->offsets, grad_table, M, m_dev, lc, grid->gridtype);
-    else
-        hipLaunchKernelGGL(k_grid_scatter<2>, g, dim3(kScThreads), 0, as_stream(stream), grad, inputs, grid->offsets, grad_table, M, m_dev, lc, grid->gridtype);
-    return check_launch("grid_scatter_lbc");
+    const rn_scatter_job_t j{grad, inputs, grid, nullptr, grad_table};
+    return rn_grid_scatter_jobs(&j, 1, M, m_dev, nullptr, 0, stream);
 }
 
 int rn_train_batch_gather(const float *table, uint32_t row_floats, const int64_t *idx, uint32_t n, const uint32_t *widths,

@@ -34,7 +34,9 @@ def exported_symbols():
 
 
 def supported(dim_in, dim_out, dim_hidden, num_layers):
-    return dim_hidden == 64 and num_layers in (2, 3) and int(_lib.rn_mlp64_image_floats(dim_in, dim_out, num_layers)) > 0 and \
+    """Hidden width 64 natively; width 32 (torso_net, nerf/network.py:165) runs on the same kernels with its hidden layers
+    zero-padded to 64 units (fused_mlp): a padded unit's pre-activation is 0, its ReLU output 0 and its weight gradients 0."""
+    return dim_hidden in (32, 64) and num_layers in (2, 3) and int(_lib.rn_mlp64_image_floats(dim_in, dim_out, num_layers)) > 0 and \
         (dim_out, num_layers) in ((65, 3), (64, 3), (2, 3), (3, 2), (4, 3), (1, 3))
 
 
@@ -102,6 +104,17 @@ def fused_mlp(x, weights, constants=None):
     inputs that are the same for every sample -- audio code, eye value, individual code) and the nn.Linear weights of the stack
     (weights[0]: [64, in_x + in_c]); differentiable in x, the constants and the weights.  The constants are never repeated:
     they enter as a bias of the first layer."""
+    weights = list(weights)
+    hidden = weights[0].shape[0]
+    if hidden != 64:
+        # width-32 stack on the 64-wide kernels: hidden units 32..63 are all-zero rows / columns (differentiable pads, so the
+        # gradients of the real weights come back through the slices)
+        pad = 64 - hidden
+        F = torch.nn.functional
+        weights[0] = F.pad(weights[0], (0, 0, 0, pad))
+        if len(weights) == 3:
+            weights[1] = F.pad(weights[1], (0, pad, 0, pad))
+        weights[-1] = F.pad(weights[-1], (0, pad))
     bias0 = None
     if constants is not None:
         in_x = x.shape[1]

@@ -251,14 +251,14 @@ class NeRFNetwork(NeRFRenderer):
         x = x * self.opt.torso_shrink
         enc_pose = self.pose_encoder(poses)
         enc_x = self.torso_deform_encoder(x)
-        parts = [enc_x, enc_pose.repeat(x.shape[0], 1)]
-        if c is not None:
-            parts.append(c.repeat(x.shape[0], 1))
-        h = torch.cat(parts, dim=-1)
-        dx = self.torso_deform_net(h)
+        # the pose encoding and the individual code are the same for every pixel of a call (the reference repeats and
+        # concatenates them, network.py:198-201): MLP.forward_split takes them as constants -- columns in the same order,
+        # [enc_x | enc_pose | c] for the deformation net and [grid | enc_x | enc_pose | c] for the torso net
+        consts = [enc_pose, c]
+        dx = self.torso_deform_net.forward_split(enc_x, consts)
         x = (x + dx).clamp(-1, 1)
         x = self.torso_encoder(x, bound=1)
-        h = self.torso_net(torch.cat([x, h], dim=-1))
+        h = self.torso_net.forward_split(torch.cat([x, enc_x], dim=-1), consts)
         return torch.sigmoid(h[..., :1]), torch.sigmoid(h[..., 1:]), dx
 
     def _geometry(self, x, enc_a, e):

@@ -21,6 +21,10 @@ _lib = hip._lib
 _ptr, _u32, _f32 = C.c_void_p, C.c_uint32, C.c_float
 
 
+class ScatterJobT(C.Structure):
+    _fields_ = [("grad", _ptr), ("inputs", _ptr), ("grid", C.POINTER(GridT)), ("offsets_host", _ptr), ("grad_table", _ptr)]
+
+
 class HeadGradsT(C.Structure):
     _fields_ = [(n, _ptr) for n in ("amb_w0", "amb_w1", "amb_w2", "sig_w0", "sig_w1", "sig_w2", "col_w0", "col_w1", "enc_a", "eye", "ind_code")]
 
@@ -34,6 +38,8 @@ _SIGS = {
     "rn_grid_scatter_lbc": [_ptr, _ptr, _u32, _ptr, C.POINTER(GridT), _ptr, _ptr],
     "rn_train_head_loss": [_ptr, _ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _u32, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_train_batch_gather": [_ptr, _u32, _ptr, _u32, C.POINTER(_u32), _u32, _ptr, _ptr],
+    "rn_grid_scatter_binned": [_ptr, _ptr, _u32, _ptr, C.POINTER(GridT), _ptr, _ptr, _ptr, C.c_size_t, _ptr],
+    "rn_grid_scatter_jobs": [C.POINTER(ScatterJobT), _u32, _u32, _ptr, _ptr, C.c_size_t, _ptr],
 }
 for _n, _a in _SIGS.items():
     getattr(_lib, _n).argtypes = _a
@@ -41,10 +47,15 @@ for _n, _a in _SIGS.items():
 for _n in ("rn_train_head_image_floats", "rn_train_head_workspace_floats", "rn_train_head_wgrad_workspace"):
     getattr(_lib, _n).restype = C.c_size_t
 _lib.rn_train_head_workspace_floats.argtypes = [_u32]
+_lib.rn_grid_scatter_workspace.restype = C.c_size_t
+_lib.rn_grid_scatter_workspace.argtypes = [_u32, C.POINTER(GridT), _ptr]
+_lib.rn_grid_scatter_binned_levels.restype = C.c_uint32
+_lib.rn_grid_scatter_binned_levels.argtypes = [C.POINTER(GridT), _ptr]
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["rn_train_head_image_floats", "rn_train_head_workspace_floats", "rn_train_head_wgrad_workspace"])
+    return sorted(list(_SIGS) + ["rn_train_head_image_floats", "rn_train_head_workspace_floats", "rn_train_head_wgrad_workspace",
+                                 "rn_grid_scatter_workspace", "rn_grid_scatter_binned_levels"])
 
 
 def supported(model):
@@ -126,7 +137,7 @@ class _HeadTrain(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev)
         g_ambient, g_amb_abs = dense(g_ambient, (M, 2)), dense(g_amb_abs, (M,))
-        g_tx, g_tw = torch.zeros_like(tx), torch.zeros_like(tw)
+        g_tx, g_tw = zero_table_gradient(enc_x, tx), torch.zeros_like(tw)
         grads = [torch.empty_like(w) for w in ws]
         g_enc_a = torch.empty(audio_dim, dtype=torch.float32, device=dev)
         g_eye = torch.empty(1, dtype=torch.float32, device=dev) if has_eye else None
@@ -143,8 +154,7 @@ class _HeadTrain(torch.autograd.Function):
             hip.call("rn_train_head_weight_grads", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), M, hip.ptr(m_dev), hip.ptr(work),
                      C.byref(hg), hip.ptr(wsp), s)
             gx, gw = _grid_desc(enc_x, tx), _grid_desc(enc_w, tw)
-            hip.call("rn_grid_scatter_lbc", g_feat[0].data_ptr(), xn.data_ptr(), M, hip.ptr(m_dev), C.byref(gx), hip.ptr(g_tx), s)
-            hip.call("rn_grid_scatter_lbc", g_feat[1].data_ptr(), wn.data_ptr(), M, hip.ptr(m_dev), C.byref(gw), hip.ptr(g_tw), s)
+            grid_scatter([(g_feat[0], xn, enc_x, gx, g_tx), (g_feat[1], wn, enc_w, gw, g_tw)], M, m_dev)
         else:
             for g in grads:
                 g.zero_()
@@ -155,6 +165,73 @@ class _HeadTrain(torch.autograd.Function):
                 g_ind.zero_()
         return (None, None, g_enc_a.view(enc_a_shape), g_eye.view(eye_shape) if g_eye is not None else None,
                 g_ind.view(ind_shape) if g_ind is not None else None, None, None, g_tx, g_tw, *grads)
+
+
+_SCATTER_WS = {}
+
+
+def binning_active():
+    import os
+    return os.environ.get("RN_SCATTER", "binned") != "lbc"
+
+
+def zero_table_gradient(enc, table):
+    """A gradient buffer for `table` ready for grid_scatter as its FIRST job: the rows of binned levels are written by the scatter
+    (every one of them, by the workgroup that owns its region), so only the other levels are cleared -- for the T = 2^19 xyz table
+    2.8 MB instead of 49 MB."""
+    gd = _grid_desc(enc, table)
+    mask = int(_lib.rn_grid_scatter_binned_levels(C.byref(gd), hip.host_offsets(enc.offsets))) if binning_active() else 0
+    if not mask:
+        return torch.zeros_like(table)
+    g = torch.empty_like(table)
+    off = enc.offsets.tolist() if not hasattr(enc, "_offsets_list") else enc._offsets_list
+    try:
+        enc._offsets_list = off
+    except AttributeError:
+        pass
+    lo = None
+    for l in range(len(off) - 1):            # runs of consecutive non-binned levels: one fill each
+        if not (mask >> l) & 1:
+            lo = off[l] if lo is None else lo
+        elif lo is not None:
+            g[lo:off[l]].zero_()
+            lo = None
+    if lo is not None:
+        g[lo:off[-1]].zero_()
+    return g
+
+
+def grid_scatter(jobs, M, m_dev):
+    """grad_table += the table gradient, for one or two grids: jobs = [(grad_lbc [L, M, 2] level-major feature gradients, inputs
+    [M, D] normalised coordinates, GridEncoder, its descriptor, grad_table), ...].  The first grid's hashed levels that are large
+    enough are summed by table region (two launches, no global atomics: the T = 2^19 xyz table), every other level of both grids
+    goes through the per-workgroup line merge in ONE launch (rn_grid_scatter_jobs).  RN_SCATTER=lbc: line merge only."""
+    import os
+    s = hip.stream()
+    grad0, _, enc0, gd0, table0 = jobs[0]
+    arr = (ScatterJobT * len(jobs))()
+    keep = []
+    for i, (grad, inputs, enc, gd, table) in enumerate(jobs):
+        arr[i].grad, arr[i].inputs, arr[i].grid, arr[i].grad_table = hip.ptr(grad), hip.ptr(inputs), C.pointer(gd), hip.ptr(table)
+        arr[i].offsets_host = None
+        keep.append(gd)
+    ws, ws_bytes = None, 0
+    if binning_active():
+        off_host = hip.host_offsets(enc0.offsets)
+        if int(_lib.rn_grid_scatter_workspace(M, C.byref(gd0), off_host)) > 256:
+            # bucket workspace: per device and grid, sized for a multiple of 65 536 rows (a step's changing sample budget does not
+            # re-allocate), zeroed once -- the bucket cursors at its start are left zero by every call
+            dev = table0.device
+            need = int(_lib.rn_grid_scatter_workspace(-(-M // 65536) * 65536, C.byref(gd0), off_host))
+            key = (dev.index if dev.index is not None else torch.cuda.current_device(), enc0.offsets.data_ptr(), int(enc0.offsets[-1]) if False else 0)
+            buf = _SCATTER_WS.get(key)
+            if buf is None or buf.numel() < need:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("grid_scatter: the bucket workspace must exist before a step is captured (take one eager step first)")
+                buf = _SCATTER_WS[key] = torch.zeros(need, dtype=torch.uint8, device=dev)
+            ws, ws_bytes = buf, buf.numel()
+            arr[0].offsets_host = C.cast(off_host, _ptr)
+    hip.call("rn_grid_scatter_jobs", arr, len(jobs), M, hip.ptr(m_dev), hip.ptr(ws), ws_bytes, s)
 
 
 def head_forward(model, xyzs, dirs, enc_a, ind_code, eye, m_dev=None):

@@ -191,15 +191,18 @@ _HOST_OFFSETS = {}
 def host_offsets(offsets):
     """Host copy (ctypes int32 array) of a grid's `offsets` buffer, made once per buffer (one synchronising copy, then
     cached on its address + version): the planned grid forward sizes its LDS staging from the level sizes."""
-    key = (offsets.data_ptr(), offsets._version, offsets.numel())
-    hit = _HOST_OFFSETS.get(key)
-    if hit is None:
-        if len(_HOST_OFFSETS) > 64:
-            _HOST_OFFSETS.clear()
-        vals = offsets.detach().to("cpu", torch.int32).tolist()
-        hit = (C.c_int32 * len(vals))(*vals)
-        _HOST_OFFSETS[key] = hit
-    return hit
+    # cached ON the tensor object (with its version): an address-keyed cache would hand a new buffer that happens to reuse a freed
+    # one's address the OLD grid's level sizes
+    hit = getattr(offsets, "_rn_host_offsets", None)
+    if hit is not None and hit[0] == offsets._version:
+        return hit[1]
+    vals = offsets.detach().to("cpu", torch.int32).tolist()
+    arr = (C.c_int32 * len(vals))(*vals)
+    try:
+        offsets._rn_host_offsets = (offsets._version, arr)
+    except AttributeError:
+        pass
+    return arr
 
 
 def workspace_bytes_grid(B, L, Cc, dtype_id):

@@ -130,3 +130,44 @@ def test_unsupported_shapes_fall_back_to_linear_layers(hiplib):
     x = torch.rand(2048, 136, device="cuda", requires_grad=True)
     y = m(x)
     assert y.shape == (2048, 4) and torch.autograd.grad(y.sum(), x)[0].shape == x.shape
+
+
+def test_torso_branch_trains_on_the_mlp_kernels(hiplib, monkeypatch):
+    """nerf/network.py:188-219 under autograd (the 200 k torso iterations of the reference's schedule): torso_deform_net (width 64)
+    and torso_net (width 32, zero-padded to the kernels' 64) through rn_mlp64_* give the loss and gradients of the nn.Linear
+    formulation; the launches of the HIP MLP path really are these kernels."""
+    from radnerf.scene import SyntheticScene, default_opt
+    from radnerf.train import SyntheticTrainStream, train_step
+    import radnerf_hip as hip
+
+    def run(mode):
+        monkeypatch.setenv("RN_MLP_TRAIN", mode)
+        torch.manual_seed(0)
+        scene = SyntheticScene(H=64, W=64, n_frames=8, device="cuda", opt=default_opt(engine="ops", torso=True, smooth_lips=False))
+        m = scene.model
+        m.train()
+        stream = SyntheticTrainStream(scene, n_rays=4096, seed=2)
+        called = []
+        real = hip.call
+
+        def spy(name, *a):
+            called.append(name)
+            return real(name, *a)
+        monkeypatch.setattr(hip, "call", spy)
+        _, _, loss = train_step(m, stream.batch(), scene.opt, global_step=1)
+        loss.backward()
+        monkeypatch.setattr(hip, "call", real)
+        names = ("torso_net", "torso_deform_net", "torso_encoder", "individual_codes_torso")
+        return float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None and n.startswith(names)}, called
+    l_t, g_t, _ = run("torch")
+    l_h, g_h, called = run("hip")
+    assert called.count("rn_mlp64_forward") == 2 and called.count("rn_mlp64_backward") == 2
+    assert abs(l_t - l_h) <= 1e-5 * max(abs(l_t), 1e-3)
+    assert set(g_t) == set(g_h) and any(n.startswith("torso_net") for n in g_t)
+    for n in g_t:
+        a, b = g_h[n], g_t[n]
+        scale = float(b.abs().max()) + 1e-20
+        cos = float(torch.nn.functional.cosine_similarity(a.reshape(1, -1).double(), b.reshape(1, -1).double()))
+        # upstream of the 2-D torso grid (deformation net, its codes) a pixel on a cell boundary may take the neighbour's derivative
+        up = n.startswith(("torso_deform_net", "individual_codes_torso"))
+        assert float((a - b).abs().max()) / scale < (3e-2 if up else 2e-3) and cos > (0.9995 if up else 0.99999), (n, cos)

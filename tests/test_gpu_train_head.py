@@ -148,8 +148,9 @@ def test_fused_head_live_count_bounds_the_rows(hiplib, monkeypatch):
         assert float((g_a[name] - g_b[name]).abs().max()) / scale < 1e-4, name
 
 
+@pytest.mark.parametrize("points", ["rays", "coincident"])
 @pytest.mark.parametrize("D", [2, 3])
-def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D):
+def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D, points):
     """rn_grid_scatter_lbc == rn_grid_encode_backward's table gradient (kernel_grid_backward, gridencoder.cu:247-339)."""
     import ctypes as C
     import radnerf_hip as hip
@@ -165,6 +166,8 @@ def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D):
     base = torch.rand(B // 16, 1, D, device="cuda", generator=g)
     x = (base + 0.02 * torch.arange(16, device="cuda").view(1, 16, 1) * torch.randn(B // 16, 1, D, device="cuda", generator=g)).reshape(-1, D)
     x = x.clamp(0, 1)
+    if points == "coincident":             # every sample in the same few cells: the buckets of those rows overflow into the spill list
+        x = x[:7].repeat(B // 7 + 1, 1)[:B]
     x[:5] = 1.5
     x = x.contiguous()
     grad_lbc = torch.randn(16, B, 2, device="cuda", generator=g)
@@ -178,8 +181,19 @@ def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D):
     hip.call("rn_grid_encode_backward", hip.ptr(gl), hip.ptr(xl), hip.ptr(enc.embeddings.detach()), hip.ptr(enc.offsets, torch.int32), hip.ptr(want),
              live, D, 2, 16, float(np.log2(enc.per_level_scale)), 16, None, None, enc.gridtype_id, 0, 0, hip.RN_F32, hip.RN_LAYOUT_LBC, hip.stream())
     scale = float(want.abs().max())
-    assert float((got - want).abs().max()) / scale < 1e-5
+    tol = 1e-5 if points == "rays" else 2e-4        # thousands of terms per row in another order
+    assert float((got - want).abs().max()) / scale < tol
     assert int((got != 0).sum()) == int((want != 0).sum())
+    # the path the training step takes (train_head.grid_scatter): hashed levels summed by table region (two launches) where the
+    # grid has such levels, called twice in a row -- the bucket cursors must come back to zero
+    for _ in range(2):
+        got2 = torch.zeros_like(enc.embeddings)
+        train_head.grid_scatter([(grad_lbc, x, enc, gd, got2)], B, cnt)
+        assert float((got2 - want).abs().max()) / scale < tol
+        assert int((got2 != 0).sum()) == int((want != 0).sum())
+    if D == 3:
+        need = int(train_head._lib.rn_grid_scatter_workspace(B, C.byref(gd), hip.host_offsets(enc.offsets)))
+        assert need > 1 << 20                      # the T = 2^19 hash table has binned levels
 
 
 def test_head_loss_kernel_matches_the_pytorch_expression(hiplib):

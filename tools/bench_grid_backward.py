@@ -48,7 +48,10 @@ def main():
             gd.embeddings, gd.offsets, gd.D, gd.L, gd.H, gd.S, gd.gridtype, gd.dtype = emb.data_ptr(), off_d.data_ptr(), D, L, 16, S, gridtype, hip.RN_F32
             g_lbc = g.view(B, L, C).permute(1, 0, 2).contiguous()
             fn2 = lambda: hip.call("rn_grid_scatter_lbc", hip.ptr(g_lbc), hip.ptr(x), B, None, C_.byref(gd), hip.ptr(ge), hip.stream())
-            for label, f in (("", fn), (" line-keyed", fn2)):
+            class _E:          # what train_head.grid_scatter reads of a GridEncoder
+                offsets = off_d
+            fn3 = lambda: train_head.grid_scatter([(g_lbc, x, _E, gd, ge)], B, None)
+            for label, f in (("", fn), (" line-keyed", fn2), (" binned", fn3)):
                 for _ in range(3):
                     f()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
