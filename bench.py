@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--loop-launch", default="split", choices=["coop", "split"],
                     help="fused engine: compositor + compaction + next march of a loop iteration in one launch with a grid-wide "
                          "barrier inside (2 launches per iteration) / a launch each for compositor and compaction (3)")
+    ap.add_argument("--half-tables", action="store_true",
+                    help="the kernels read persistent fp16 copies of the grid tables (opt.half_tables; what load_checkpoint(half_tables=True) "
+                         "sets up) -- with --mlp f16 the reference's -O mode without its per-call table casts (gridencoder/grid.py:43-44)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-record", action="store_true",
                     help="skip the bounded config[2] run (64 graph-replayed training steps) that the default single-GPU render line "
@@ -328,7 +331,8 @@ def main():
     K, W = args.steps, args.warmup
     n_frames = 250
     scene = SyntheticScene(H=size, W=size, n_frames=n_frames, device=device,
-                           opt=default_opt(engine=engine, mlp_dtype=args.mlp, loop_launch=args.loop_launch, **GRIDS[args.grid]))
+                           opt=default_opt(engine=engine, mlp_dtype=args.mlp, loop_launch=args.loop_launch, half_tables=args.half_tables,
+                                           **GRIDS[args.grid]))
     if args.regime == "A":
         with torch.no_grad():
             scene.model.sigma_net.net[-1].weight[0].abs_().mul_(80.0)
@@ -487,7 +491,7 @@ def main():
                                     f"config[{1 if world == 1 else 3}]: inference {size}x{size}, ") + f"{GRID_TEXT[args.grid]}, "
                                    "max 16 steps/ray, 25 FPS pose stream, torso pass on"
                                    + (", regime A (opaque: sigma ~ 20..300 inside the head, rays terminate on T < 1e-4)" if args.regime == "A" else ""),
-                       "grid": args.grid, "engine": engine, "frames_per_gpu": K,
+                       "grid": args.grid, "engine": engine, "frames_per_gpu": K, "table_dtype": "f16 (persistent copies)" if args.half_tables else "f32",
                        "scene": {"occupancy_ellipsoid_semi_axes": [0.40, 0.42, 0.40], "camera": "OrbitCamera radius 3.35, fovy 21.24 deg, "
                                  "yaw 8 deg sin(2 pi t / 4 s), pitch 4 deg sin(2 pi t / 2.5 s)", "regime": args.regime,
                                  "note": "SURVEY 8(d) proposes semi-axes (0.33, 0.42, 0.33); (0.40, 0.42, 0.40) reproduces the published "

@@ -95,6 +95,19 @@ class HipAdam:
 
     @torch.no_grad()
     def step(self):
+        import sys
+        th = sys.modules.get("radnerf.train_head")
+        if th is not None:                       # table-gradient scatters still running on the side stream (train_head.deferred_join)
+            pending = th.take_pending_events()
+            if pending:
+                held = {p.grad.data_ptr() for g in self.param_groups for p in g["params"] if p.grad is not None}
+                for ev, *ptrs in pending:
+                    torch.cuda.current_stream().wait_event(ev)
+                    if not all(q in held for q in ptrs):
+                        # autograd copied a table gradient instead of keeping the buffer the scatter writes (a parameter that
+                        # already had a .grad): that copy raced with the side stream
+                        raise RuntimeError("HipAdam: a table gradient was copied before its scatter had finished; use "
+                                           "zero_grad(set_to_none=True) or RN_TRAIN_OVERLAP=0")
         entries, keep, written, groups = [], [], [], []
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
@@ -283,10 +296,30 @@ class Trainer:
                 m.update_extra_state()
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=True)
-        _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
-        loss.backward()
-        self.optimizer.step()
+        with _join_in_optimizer(self.optimizer):
+            _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
+            loss.backward()
+            self.optimizer.step()
         return loss.detach()
+
+
+class _join_in_optimizer:
+    """HipAdam.step waits for the table-gradient scatter the backward pass left on a side stream (train_head.deferred_join); any
+    other optimizer gets gradients that are complete when backward() returns."""
+
+    def __init__(self, optimizer):
+        self.ctx = None
+        if isinstance(optimizer, HipAdam) and torch.cuda.is_available():
+            from . import train_head
+            self.ctx = train_head.deferred_join()
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 class GraphedTrainer(Trainer):
@@ -336,7 +369,7 @@ class GraphedTrainer(Trainer):
         m._static_counter = self._counter                     # renderer._head_training counts into this pair while captured
         m._sample_budget = (self._budget, self._capacity)
         try:
-            with torch.cuda.graph(g):                    # a private memory pool per graph: cached graphs never alias each other
+            with torch.cuda.graph(g), _join_in_optimizer(self.optimizer):   # a private memory pool per graph: cached graphs never alias each other
                 _, _, loss = train_step(m, self._static, self.opt, amb_weight=self._amb_weight)
                 loss.backward()
                 self.optimizer.step()
@@ -360,9 +393,10 @@ class GraphedTrainer(Trainer):
         self.global_step += 1
         if m.mean_count <= 0 or not next(m.parameters()).is_cuda:        # first window / CPU: the eager step
             self.optimizer.zero_grad(set_to_none=True)
-            _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
-            loss.backward()
-            self.optimizer.step()
+            with _join_in_optimizer(self.optimizer):
+                _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
+                loss.backward()
+                self.optimizer.step()
             return loss.detach()
         budget = int(m.mean_count)
         budget += 128 - budget % 128                                     # raymarching.py:226-229 (align = 128)
