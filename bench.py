@@ -261,17 +261,17 @@ def train_record(args, device_index=0):
         # 16 x 4 x 8 B + 128 B + 8 B for the ambient grid: the call covers both (3 launches)
         per_launch = probe_samples * ((1024 + 128 + 12) + (512 + 128 + 8))
         ach = per_launch / (res["avg_ms"] * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="k_grid_bin<3> + k_grid_scatter_buckets + k_grid_scatter<3,2> (table-gradient scatter-add of the xyz and ambient grids)", achieved=ach, peak=HBM_PEAK_GBS,
+        roof = dict(bound="hbm", kernel="k_grid_scatter<3,2> (table-gradient scatter-add of the xyz and ambient grids, one launch)", achieved=ach, peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, launches=res["launches"], avg_launch_ms=res["avg_ms"],
                     algorithmic_bytes_per_launch=per_launch, samples_per_launch=probe_samples,
                     share_of_step=res["avg_ms"] * ((samples / K) / max(probe_samples, 1.0)) / (elapsed / K * 1e3),
                     source="HIP events around the kernel's C-ABI call in %d eagerly enqueued steps right after the timed region "
                            "(a replayed hipGraph has no per-kernel events); share_of_step scales the duration to the timed region's "
                            "samples per step" % n_probe,
-                    note="the hashed levels of the T = 2^19 table are summed by table region (entries binned per 4096-row bucket, one "
-                         "workgroup per bucket adds them in LDS and writes the region: no global atomics, ~3x the algorithmic bytes in "
-                         "entry traffic); the dense levels and the ambient grid go through an LDS merge per 64-B line + one float-atomic "
-                         "request per touched line (memory-side atomics: ~20 G requests/s chip-wide)")
+                    note="a workgroup merges its samples' rows per 64-B line of the gradient table in LDS, then issues one float-atomic "
+                         "request per touched line (memory-side atomics: ~20 G requests/s chip-wide; LDS float atomics: 3.6 clocks per "
+                         "lane): bound by those two rates, not by bytes.  The call runs on a side stream beside the weight-gradient and "
+                         "audio-backward kernels, so its duration here includes that contention")
     sps = [1e3 / t for t in seg_ms]
     return ({
         "metric": "training steps/sec @4096 rays", "value": K / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": W,

@@ -150,7 +150,7 @@ def test_fused_head_live_count_bounds_the_rows(hiplib, monkeypatch):
 
 @pytest.mark.parametrize("points", ["rays", "coincident"])
 @pytest.mark.parametrize("D", [2, 3])
-def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D, points):
+def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, monkeypatch, D, points):
     """rn_grid_scatter_lbc == rn_grid_encode_backward's table gradient (kernel_grid_backward, gridencoder.cu:247-339)."""
     import ctypes as C
     import radnerf_hip as hip
@@ -184,8 +184,9 @@ def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, D, points):
     tol = 1e-5 if points == "rays" else 2e-4        # thousands of terms per row in another order
     assert float((got - want).abs().max()) / scale < tol
     assert int((got != 0).sum()) == int((want != 0).sum())
-    # the path the training step takes (train_head.grid_scatter): hashed levels summed by table region (two launches) where the
+    # the opt-in table-region sum (RN_SCATTER=binned): hashed levels binned + one workgroup per bucket (two launches) where the
     # grid has such levels, called twice in a row -- the bucket cursors must come back to zero
+    monkeypatch.setenv("RN_SCATTER", "binned")
     for _ in range(2):
         got2 = torch.zeros_like(enc.embeddings)
         train_head.grid_scatter([(grad_lbc, x, enc, gd, got2)], B, cnt)
