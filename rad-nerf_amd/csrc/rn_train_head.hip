@@ -279,6 +279,7 @@ __device__ __forceinline__ uint32_t live_count(uint32_t M, const int32_t *m_dev)
     return d <= 0 ? 0u : ((uint32_t)d < M ? (uint32_t)d : M);
 }
 
+template <int GX, int GA>   // gather rounds in flight per wave (xyz grid / ambient grid): independent load chains hide each other's latency
 __global__ void __launch_bounds__(kThreads) k_train_fwd(FwdParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kFwd + kBias];
     __shared__ LevelPlan plan_x[16], plan_w[16];
@@ -320,23 +321,30 @@ __global__ void __launch_bounds__(kThreads) k_train_fwd(FwdParams p) {
                 if (h == 0) { p.xn[3 * (size_t)sample] = in[0]; p.xn[3 * (size_t)sample + 1] = in[1]; p.xn[3 * (size_t)sample + 2] = in[2]; }
             }
             float *ex = ws.ex + (size_t)tile * kTile16;
-            LevelFetch<float, 3, 2> f;
+            LevelFetch<float, 3, 2> f[GX];
 #pragma unroll 1
-            for (int r = 0; r < 8; r++) {
-                float f0 = 0.0f, f1 = 0.0f;
+            for (int r0 = 0; r0 < 8; r0 += GX) {
                 if (on) {
-                    issue_planned<float, 3, 2, false, false>(tx, plan_x[2 * r + h], in, f);
-                    float res[2], dummy[1];
-                    blend_level<float, 3, 2, false>(f, 0.0f, res, dummy);
-                    f0 = res[0];
-                    f1 = res[1];
+#pragma unroll
+                    for (int i = 0; i < GX; i++) issue_planned<float, 3, 2, false, false>(tx, plan_x[2 * (r0 + i) + h], in, f[i]);
                 }
-                step32(a0, lds + F_A0, 2 * r, lane_off, f0);
-                step32(a2, lds + F_S0, 2 * r, lane_off, f0);
-                step32(a0, lds + F_A0, 2 * r + 1, lane_off, f1);
-                step32(a2, lds + F_S0, 2 * r + 1, lane_off, f1);
-                ex[(2 * r) * 64 + lane] = f0;
-                ex[(2 * r + 1) * 64 + lane] = f1;
+#pragma unroll
+                for (int i = 0; i < GX; i++) {
+                    const int r = r0 + i;
+                    float f0 = 0.0f, f1 = 0.0f;
+                    if (on) {
+                        float res[2], dummy[1];
+                        blend_level<float, 3, 2, false>(f[i], 0.0f, res, dummy);
+                        f0 = res[0];
+                        f1 = res[1];
+                    }
+                    step32(a0, lds + F_A0, 2 * r, lane_off, f0);
+                    step32(a2, lds + F_S0, 2 * r, lane_off, f0);
+                    step32(a0, lds + F_A0, 2 * r + 1, lane_off, f1);
+                    step32(a2, lds + F_S0, 2 * r + 1, lane_off, f1);
+                    ex[(2 * r) * 64 + lane] = f0;
+                    ex[(2 * r + 1) * 64 + lane] = f1;
+                }
             }
         }
         // ---- ambient net: [enc_x | enc_a] 96 -> 64 -> 64 -> 2, tanh
@@ -362,26 +370,32 @@ __global__ void __launch_bounds__(kThreads) k_train_fwd(FwdParams p) {
                 p.wn[2 * (size_t)sample + 1] = in[1];
             }
             float *ew = ws.ew + (size_t)tile * kTile16, *dw = ws.dw + (size_t)tile * kTile32;
-            LevelFetch<float, 2, 2> f;
+            LevelFetch<float, 2, 2> f[GA];
 #pragma unroll 1
-            for (int r = 0; r < 8; r++) {
-                float f0 = 0.0f, f1 = 0.0f, g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int r0 = 0; r0 < 8; r0 += GA) {
                 if (on) {
-                    const LevelPlan &lp = plan_w[2 * r + h];
-                    issue_planned<float, 2, 2, false, false>(tw, lp, in, f);
-                    float res[2], grads[4];
-                    blend_level<float, 2, 2, true>(f, lp.scale, res, grads);
-                    f0 = res[0];
-                    f1 = res[1];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) g[q] = grads[q];
+                    for (int i = 0; i < GA; i++) issue_planned<float, 2, 2, false, false>(tw, plan_w[2 * (r0 + i) + h], in, f[i]);
                 }
-                step32(a2, lds + F_S0, 16 + 2 * r, lane_off, f0);
-                step32(a2, lds + F_S0, 16 + 2 * r + 1, lane_off, f1);
-                ew[(2 * r) * 64 + lane] = f0;
-                ew[(2 * r + 1) * 64 + lane] = f1;
 #pragma unroll
-                for (int q = 0; q < 4; q++) dw[(4 * r + q) * 64 + lane] = g[q];
+                for (int i = 0; i < GA; i++) {
+                    const int r = r0 + i;
+                    float f0 = 0.0f, f1 = 0.0f, g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (on) {
+                        float res[2], grads[4];
+                        blend_level<float, 2, 2, true>(f[i], plan_w[2 * r + h].scale, res, grads);
+                        f0 = res[0];
+                        f1 = res[1];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) g[q] = grads[q];
+                    }
+                    step32(a2, lds + F_S0, 16 + 2 * r, lane_off, f0);
+                    step32(a2, lds + F_S0, 16 + 2 * r + 1, lane_off, f1);
+                    ew[(2 * r) * 64 + lane] = f0;
+                    ew[(2 * r + 1) * 64 + lane] = f1;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dw[(4 * r + q) * 64 + lane] = g[q];
+                }
             }
         }
         // ---- sigma net: [enc_x | enc_w | eye] 65 -> 64 -> 64 -> 1 + 64
@@ -1181,7 +1195,7 @@ static uint32_t wparts() {   // workgroups (= partial sums) per weight-gradient 
     static uint32_t n = 0;
     if (!n) {
         const char *e = getenv("RN_TRAIN_WPARTS");
-        const long v = e ? atol(e) : 96;
+        const long v = e ? atol(e) : 128;          // measured at 62 k samples: 64 parts 76 us, 96: 80, 128: 71, 192: 85
         n = (uint32_t)(v < 1 ? 1 : (v > (long)kWPartsMax ? (long)kWPartsMax : v));
     }
     return n;
@@ -1238,7 +1252,12 @@ int rn_train_head_forward(const float *xyzs, const float *dirs, uint32_t M, cons
     uint32_t blocks = div_up(n_tiles, kWaves);
     const uint32_t cap = (uint32_t)num_cus();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_train_fwd, dim3(blocks), dim3(kThreads), 0, as_stream(stream), p);
+    static int groups = -1;
+    if (groups < 0) { const char *e = getenv("RN_TRAIN_FWD_GROUPS"); groups = e ? atoi(e) : 11; }
+    // measured at 62 k samples (tools/bench_train_head.py): <1,1> 82.5 us, <1,2> 82.4, <2,2> 84.5, <2,4> 85.9 -- with one tile per
+    // wave the two waves of a SIMD already hide each other's gathers; more rounds in flight only cost registers
+    if (groups == 12) hipLaunchKernelGGL((k_train_fwd<1, 2>), dim3(blocks), dim3(kThreads), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_train_fwd<1, 1>), dim3(blocks), dim3(kThreads), 0, as_stream(stream), p);
     return check_launch("train_head_forward");
 }
 

@@ -173,7 +173,7 @@ class NeRFRenderer(nn.Module):
             self.last_stats["live_samples"] = int(live.item())
         return acc
 
-    def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps):
+    def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps, wait_for=None):
         """Train branch (renderer.py:206-223): every sample of every ray, packed; one sample counter per step (ring of 16)."""
         counter = getattr(self, "_static_counter", None)           # a captured training step counts into a fixed pair
         if counter is None:
@@ -190,6 +190,11 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
+        if wait_for is not None:                 # the audio code was computed on a side stream (run_cuda)
+            main = torch.cuda.current_stream(xyzs.device)
+            main.wait_stream(wait_for)
+            if torch.is_tensor(enc_a):
+                enc_a.record_stream(main)
         from .network import _train_glue, _train_head
         th = _train_head()
         if th is not None and th.usable(self, xyzs, enc_a):
@@ -268,8 +273,23 @@ class NeRFRenderer(nn.Module):
             return results
 
         box = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = (t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
-        enc_a = self._audio_code(auds)
+        # training on the GPU: the audio nets (four latency-bound launches) run on a side stream beside near/far and the marcher,
+        # which need nothing of them; the stream that owns the step waits just before the network kernel reads the code
+        audio_side = None
+        if self.training and rays_o.is_cuda and torch.is_grad_enabled() and auds is not None and auds.is_cuda:
+            from .network import _train_head
+            th = _train_head()
+            if th is not None and th.overlap_enabled():
+                audio_side = th.side_stream(rays_o.device, 1)
+        if audio_side is not None:
+            main = torch.cuda.current_stream(rays_o.device)
+            audio_side.wait_stream(main)
+            with torch.cuda.stream(audio_side):
+                enc_a = self._audio_code(auds)
+            nears, fars = (t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
+        else:
+            nears, fars = (t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
+            enc_a = self._audio_code(auds)
         ind_code = None
         if self.individual_dim > 0:
             if self.training and not isinstance(index, int):
@@ -291,7 +311,8 @@ class NeRFRenderer(nn.Module):
 
         results = {}
         if self.training:
-            head = self._head_training(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps)
+            head = self._head_training(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps,
+                                       wait_for=audio_side)
             results["weights_sum"], results["ambient"] = head["weights_sum"], head["ambient"]
         else:
             head = self._head_inference_ops(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps, T_thresh)

@@ -212,12 +212,18 @@ def overlap_enabled():
     return os.environ.get("RN_TRAIN_OVERLAP", "1") == "1"
 
 
-def _side_stream(dev):
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+def side_stream(dev, which=0):
+    """Side streams of the training step: 0 = table-gradient scatter (backward), 1 = audio nets (forward; their backward follows
+    them there, autograd runs an op's backward on its forward's stream)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
     st = _SIDE.get(key)
     if st is None:
         st = _SIDE[key] = torch.cuda.Stream(device=dev)
     return st
+
+
+def _side_stream(dev):
+    return side_stream(dev, 0)
 
 
 def take_pending_events():
