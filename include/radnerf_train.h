@@ -102,7 +102,10 @@ uint32_t rn_grid_scatter_binned_levels(const rn_grid_t *grid, const int32_t *off
 typedef struct {
     const float *grad, *inputs;      /* [L, M, 2] level-major feature gradients, [M, D] normalised coordinates */
     const rn_grid_t *grid;
-    const int32_t *offsets_host;     /* host copy of grid->offsets (job 0, nullable: no binning) */
+    const int32_t *offsets_host;     /* host copy of grid->offsets (nullable).  With it the library knows which levels are hashed:
+                                        large hashed levels skip the LDS merge (a workgroup never touches one of their lines twice)
+                                        and send each x-pair's four floats from four adjacent lanes -- one request per pair; job 0's
+                                        may additionally be binned when a workspace is given */
     float *grad_table;
 } rn_scatter_job_t;
 int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t M, const int32_t *m_dev, void *workspace,

@@ -856,6 +856,7 @@ struct ScatterJob {
     LevelConsts lc;
     uint32_t gridtype, n_levels;
     uint32_t level_of[kMaxLevels];    // the levels this job covers (blockIdx.y indexes this list)
+    uint32_t direct_mask;             // bit i: entry i of level_of goes straight to memory (a hashed level: nothing to merge)
 };
 
 template <uint32_t D>
@@ -864,9 +865,12 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
     constexpr uint32_t kScSamples = kScThreads / P;  // lanes 0 .. S-1: pair 0 of the S samples, lanes S .. 2S-1: pair 1, ...
     if (blockIdx.y >= j.n_levels || blockIdx.x * kScSamples >= M) return;
     const uint32_t level = j.level_of[blockIdx.y];
-    for (uint32_t i = threadIdx.x; i < kScSlots; i += kScThreads) keys[i] = kScEmpty;
-    for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) vals[i] = 0.0f;
-    __syncthreads();
+    const bool direct = (j.direct_mask >> blockIdx.y) & 1u;   // workgroup-uniform
+    if (!direct) {
+        for (uint32_t i = threadIdx.x; i < kScSlots; i += kScThreads) keys[i] = kScEmpty;
+        for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) vals[i] = 0.0f;
+        __syncthreads();
+    }
     const uint32_t off = (uint32_t)j.offsets[level];
     const uint32_t hashmap_size = (uint32_t)j.offsets[level + 1] - off;
     float *gg = j.grad_grid + (size_t)off * 2;
@@ -904,6 +908,23 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
             row1 = grid_row<D>(j.gridtype, false, hashmap_size, resolution, pgl);
         }
         float v[4] = {wyz[0] * g.x, wyz[0] * g.y, wyz[1] * g.x, wyz[1] * g.y};
+        if (direct) {
+            // A hashed level: the workgroup's samples never touch a line twice, so an LDS merge would spend ~3.6 clocks per lane
+            // and float on LDS atomics to remove nothing.  The four floats of an x-pair (two rows that share a 64-B line 7 times out
+            // of 8) leave from four ADJACENT lanes of one instruction -- one memory-side request per pair: instruction k serves the
+            // pairs of lanes 16 k .. 16 k + 15, lane l carrying float (l & 3) of pair 16 k + (l >> 2).
+            const uint32_t lane = threadIdx.x & 63u, f = lane & 3u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const int src = (int)(16u * k + (lane >> 2));
+                const uint32_t r0 = (uint32_t)__shfl((int)row0, src, 64), r1 = (uint32_t)__shfl((int)row1, src, 64);
+                const float a0 = __shfl(v[0], src, 64), a1 = __shfl(v[1], src, 64), a2 = __shfl(v[2], src, 64), a3 = __shfl(v[3], src, 64);
+                const uint32_t row = f < 2u ? r0 : r1;
+                const float val = f == 0u ? a0 : (f == 1u ? a1 : (f == 2u ? a2 : a3));
+                if (row != kScEmpty && val != 0.0f) atomicAdd(gg + (size_t)row * 2 + (f & 1u), val);
+            }
+            return;
+        }
         if (merge_runs4(row0, row1, v)) {
             const uint32_t rows[2] = {row0, row1};
 #pragma unroll
@@ -1354,6 +1375,11 @@ static uint32_t plan_bins(const rn_grid_t *grid, const int32_t *offsets_host, ui
     bp.cap = total ? (uint32_t)(2u * (((uint64_t)M << grid->D) / min_b) + 2048u) : 0u;   // 2 x the mean load of a bucket + slack
     return total;
 }
+static bool scatter_direct_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RN_SCATTER_DIRECT"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
 static ScatterJob make_job(const rn_scatter_job_t &j) {
     ScatterJob s{};
     s.grad = j.grad;
@@ -1413,7 +1439,7 @@ int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t
     bool binned[kMaxLevels] = {};
     BinPlan bp{};
     uint32_t total = 0;
-    if (jobs[0].offsets_host && workspace) {
+    if (jobs[0].offsets_host && workspace && workspace_bytes > 256) {
         total = plan_bins(jobs[0].grid, jobs[0].offsets_host, M, bp, binned);
         if (total) {
             RN_REQUIRE(((uintptr_t)workspace & 255u) == 0 && workspace_bytes >= rn_grid_scatter_workspace(M, jobs[0].grid, jobs[0].offsets_host),
@@ -1435,8 +1461,23 @@ int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t
     }
     uint32_t max_levels = 0, max_blocks = 0;
     for (uint32_t i = 0; i < n_jobs; i++) {
-        for (uint32_t l = 0; l < jobs[i].grid->L; l++)
-            if (!(i == 0 && total && binned[l])) sj[i].level_of[sj[i].n_levels++] = l;
+        const rn_grid_t *gr = jobs[i].grid;
+        const LevelConsts lc = make_level_consts(gr->L, gr->S, gr->H);
+        for (uint32_t l = 0; l < gr->L; l++) {
+            if (i == 0 && total && binned[l]) continue;
+            // hashed (gridencoder.cu:66-84) AND large (>= 2^17 rows: a workgroup's 64 samples x 8 corners land on distinct
+            // lines): straight to memory.  Needs a host view of the level sizes: jobs[i].offsets_host (else: line merge)
+            bool direct = false;
+            if (jobs[i].offsets_host && scatter_direct_enabled()) {
+                const uint32_t rows = (uint32_t)(jobs[i].offsets_host[l + 1] - jobs[i].offsets_host[l]);
+                uint64_t stride = 1;
+                for (uint32_t d = 0; d < gr->D; d++)
+                    if (stride <= rows) stride *= (uint64_t)lc.resolution[l] + 1u;
+                direct = gr->gridtype == 0 && stride > rows && rows >= (1u << 17);
+            }
+            if (direct) sj[i].direct_mask |= 1u << sj[i].n_levels;
+            sj[i].level_of[sj[i].n_levels++] = l;
+        }
         if (sj[i].n_levels > max_levels) max_levels = sj[i].n_levels;
         const uint32_t blocks = div_up(M, kScThreads >> (jobs[i].grid->D - 1));
         if (blocks > max_blocks) max_blocks = blocks;

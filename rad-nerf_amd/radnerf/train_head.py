@@ -294,8 +294,9 @@ def grid_scatter(jobs, M, m_dev):
     keep = []
     for i, (grad, inputs, enc, gd, table) in enumerate(jobs):
         arr[i].grad, arr[i].inputs, arr[i].grid, arr[i].grad_table = hip.ptr(grad), hip.ptr(inputs), C.pointer(gd), hip.ptr(table)
-        arr[i].offsets_host = None
-        keep.append(gd)
+        off = hip.host_offsets(enc.offsets)        # lets the library tell hashed levels (straight to memory) from dense ones
+        arr[i].offsets_host = C.cast(off, _ptr)
+        keep += [gd, off]
     ws, ws_bytes = None, 0
     if binning_active():
         off_host = hip.host_offsets(enc0.offsets)

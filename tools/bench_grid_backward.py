@@ -51,7 +51,15 @@ def main():
             class _E:          # what train_head.grid_scatter reads of a GridEncoder
                 offsets = off_d
             fn3 = lambda: train_head.grid_scatter([(g_lbc, x, _E, gd, ge)], B, None)
-            for label, f in (("", fn), (" line-keyed", fn2), (" binned", fn3)):
+            def fn4():
+                os.environ["RN_SCATTER"] = "binned"
+                try:
+                    train_head.grid_scatter([(g_lbc, x, _E, gd, ge)], B, None)
+                finally:
+                    os.environ["RN_SCATTER"] = "lbc"
+            # line-keyed = rn_grid_scatter_lbc (LDS line merge on every level); default = train_head.grid_scatter (hashed levels
+            # straight to memory from adjacent lanes, the others line-merged); binned = hashed levels summed by table region
+            for label, f in (("", fn), (" line-keyed", fn2), (" default", fn3), (" binned", fn4)):
                 for _ in range(3):
                     f()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
