@@ -860,10 +860,10 @@ struct ScatterJob {
 };
 
 template <uint32_t D>
-__device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap, uint32_t M, uint32_t *keys, float *vals) {
+__device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap, uint32_t M, uint32_t *keys, float *vals, uint32_t block_x) {
     constexpr uint32_t P = 1u << (D - 1);            // x-pairs of corners per sample
     constexpr uint32_t kScSamples = kScThreads / P;  // lanes 0 .. S-1: pair 0 of the S samples, lanes S .. 2S-1: pair 1, ...
-    if (blockIdx.y >= j.n_levels || blockIdx.x * kScSamples >= M) return;
+    if (blockIdx.y >= j.n_levels || block_x * kScSamples >= M) return;
     const uint32_t level = j.level_of[blockIdx.y];
     const bool direct = (j.direct_mask >> blockIdx.y) & 1u;   // workgroup-uniform
     if (!direct) {
@@ -874,7 +874,7 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
     const uint32_t off = (uint32_t)j.offsets[level];
     const uint32_t hashmap_size = (uint32_t)j.offsets[level + 1] - off;
     float *gg = j.grad_grid + (size_t)off * 2;
-    const uint32_t b = blockIdx.x * kScSamples + (threadIdx.x & (kScSamples - 1u));
+    const uint32_t b = block_x * kScSamples + (threadIdx.x & (kScSamples - 1u));
     const uint32_t q = threadIdx.x / kScSamples;      // this thread's x-pair: bits of q = the y (, z) corner
     float in[D];
     bool live = b < M;
@@ -958,14 +958,18 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
     }
 }
 
-// One launch for the line-merged levels of up to two grids (blockIdx.z = job: the 3-D grid's non-binned levels and the 2-D grid)
+// One launch for the levels of up to two grids that are not binned (the 3-D grid's and the 2-D grid's)
 template <uint32_t D0, uint32_t D1>
-__global__ void __launch_bounds__(kScThreads) k_grid_scatter(ScatterJob j0, ScatterJob j1, uint32_t Mcap, const int32_t *__restrict__ m_dev) {
+__global__ void __launch_bounds__(kScThreads) k_grid_scatter(ScatterJob j0, ScatterJob j1, uint32_t n_jobs, uint32_t Mcap,
+                                                             const int32_t *__restrict__ m_dev) {
     __shared__ uint32_t keys[kScSlots];
     __shared__ __attribute__((aligned(16))) float vals[kScSlots * 16];
     const uint32_t M = live_count(Mcap, m_dev);
-    if (blockIdx.z == 0) scatter_lines<D0>(j0, Mcap, M, keys, vals);
-    else scatter_lines<D1>(j1, Mcap, M, keys, vals);
+    // two jobs: their workgroups ALTERNATE along x, so that the two grids' work is resident together -- one grid's levels are bound
+    // by memory-side atomic requests, the other's by LDS atomics
+    if (n_jobs == 1) scatter_lines<D0>(j0, Mcap, M, keys, vals, blockIdx.x);
+    else if ((blockIdx.x & 1u) == 0) scatter_lines<D0>(j0, Mcap, M, keys, vals, blockIdx.x >> 1);
+    else scatter_lines<D1>(j1, Mcap, M, keys, vals, blockIdx.x >> 1);
 }
 
 // Binned levels.  A level whose gradient table is much larger than what one workgroup's samples touch (the hashed levels of the
@@ -1391,9 +1395,10 @@ static ScatterJob make_job(const rn_scatter_job_t &j) {
     return s;
 }
 template <uint32_t D0>
-static void launch_lines(uint32_t D1, dim3 g, hipStream_t s, const ScatterJob &a, const ScatterJob &b, uint32_t M, const int32_t *m_dev) {
-    if (D1 == 3) hipLaunchKernelGGL((k_grid_scatter<D0, 3>), g, dim3(kScThreads), 0, s, a, b, M, m_dev);
-    else hipLaunchKernelGGL((k_grid_scatter<D0, 2>), g, dim3(kScThreads), 0, s, a, b, M, m_dev);
+static void launch_lines(uint32_t D1, dim3 g, hipStream_t s, const ScatterJob &a, const ScatterJob &b, uint32_t n_jobs, uint32_t M,
+                         const int32_t *m_dev) {
+    if (D1 == 3) hipLaunchKernelGGL((k_grid_scatter<D0, 3>), g, dim3(kScThreads), 0, s, a, b, n_jobs, M, m_dev);
+    else hipLaunchKernelGGL((k_grid_scatter<D0, 2>), g, dim3(kScThreads), 0, s, a, b, n_jobs, M, m_dev);
 }
 
 }  // namespace th
@@ -1492,10 +1497,10 @@ int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t
         hipLaunchKernelGGL(k_grid_scatter_buckets, dim3(total), dim3(kBkThreads), shm, s, jobs[0].grid->offsets, jobs[0].grad_table, bp, total);
     }
     if (max_levels) {
-        const dim3 g(max_blocks, max_levels, n_jobs);
+        const dim3 g(n_jobs == 2 ? 2 * max_blocks : max_blocks, max_levels);
         const uint32_t D1 = n_jobs == 2 ? jobs[1].grid->D : 2u;
-        if (jobs[0].grid->D == 3) launch_lines<3>(D1, g, s, sj[0], sj[1], M, m_dev);
-        else launch_lines<2>(D1, g, s, sj[0], sj[1], M, m_dev);
+        if (jobs[0].grid->D == 3) launch_lines<3>(D1, g, s, sj[0], sj[1], n_jobs, M, m_dev);
+        else launch_lines<2>(D1, g, s, sj[0], sj[1], n_jobs, M, m_dev);
     }
     return check_launch("grid_scatter_jobs");
 }
