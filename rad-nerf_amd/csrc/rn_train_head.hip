@@ -857,25 +857,34 @@ struct ScatterJob {
     uint32_t gridtype, n_levels;
     uint32_t level_of[kMaxLevels];    // the levels this job covers (blockIdx.y indexes this list)
     uint32_t direct_mask;             // bit i: entry i of level_of goes straight to memory (a hashed level: nothing to merge)
+    uint32_t chunks_of[kMaxLevels];   // line-merged levels: chunks of samples a workgroup sums in its LDS table before it flushes
 };
 
 template <uint32_t D>
-__device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap, uint32_t M, uint32_t *keys, float *vals, uint32_t block_x) {
+__device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap, uint32_t M, uint32_t *keys, float *vals, uint32_t *occupied,
+                                              uint32_t block_x) {
     constexpr uint32_t P = 1u << (D - 1);            // x-pairs of corners per sample
     constexpr uint32_t kScSamples = kScThreads / P;  // lanes 0 .. S-1: pair 0 of the S samples, lanes S .. 2S-1: pair 1, ...
-    if (blockIdx.y >= j.n_levels || block_x * kScSamples >= M) return;
+    if (blockIdx.y >= j.n_levels) return;
     const uint32_t level = j.level_of[blockIdx.y];
     const bool direct = (j.direct_mask >> blockIdx.y) & 1u;   // workgroup-uniform
+    // small levels (few lines in all): a workgroup sums several chunks of samples in its table before it flushes -- the more
+    // samples share a table, the more of their rows coincide (the ambient coordinates of a step cluster in a few cells)
+    const uint32_t chunks = direct ? 1u : j.chunks_of[blockIdx.y];
+    if (block_x * chunks * kScSamples >= M) return;
     if (!direct) {
         for (uint32_t i = threadIdx.x; i < kScSlots; i += kScThreads) keys[i] = kScEmpty;
         for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) vals[i] = 0.0f;
+        if (threadIdx.x == 0) *occupied = 0u;
         __syncthreads();
     }
     const uint32_t off = (uint32_t)j.offsets[level];
     const uint32_t hashmap_size = (uint32_t)j.offsets[level + 1] - off;
     float *gg = j.grad_grid + (size_t)off * 2;
-    const uint32_t b = block_x * kScSamples + (threadIdx.x & (kScSamples - 1u));
     const uint32_t q = threadIdx.x / kScSamples;      // this thread's x-pair: bits of q = the y (, z) corner
+    const uint32_t resolution = j.lc.resolution[level];
+  for (uint32_t chunk = 0; chunk < chunks; chunk++) {
+    const uint32_t b = (block_x * chunks + chunk) * kScSamples + (threadIdx.x & (kScSamples - 1u));
     float in[D];
     bool live = b < M;
 #pragma unroll
@@ -888,7 +897,6 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
     lattice_pos<D>(in, j.lc.scale[level], false, 0, pos, pos_deriv, pos_grid);
     float2 g = make_float2(0.0f, 0.0f);
     if (live) g = *reinterpret_cast<const float2 *>(j.grad + ((size_t)level * Mcap + b) * 2);
-    const uint32_t resolution = j.lc.resolution[level];
     {
         uint32_t pgl[D];
         pgl[0] = pos_grid[0];
@@ -934,6 +942,7 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
                 bool placed = false;
                 for (uint32_t probe = 0; probe < kScProbes; probe++) {
                     const uint32_t prev = atomicCAS(&keys[slot], kScEmpty, line);
+                    if (prev == kScEmpty) atomicAdd(occupied, 1u);
                     if (prev == kScEmpty || prev == line) { placed = true; break; }
                     slot = (slot + 1u) & (kScSlots - 1u);
                 }
@@ -947,16 +956,30 @@ __device__ __forceinline__ void scatter_lines(const ScatterJob &j, uint32_t Mcap
             }
         }
     }
-    __syncthreads();
+    // flush when the table is filling up (spread-out samples: every chunk; clustered ones: rarely) or after the last chunk.
     // 16 adjacent lanes = the 16 floats of one 64-B line of the gradient table: one memory-side request per touched line
-    for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) {
-        const uint32_t line = keys[i >> 4];
-        if (line != kScEmpty) {
-            const float v = vals[i];
-            if (v != 0.0f) atomicAdd(gg + (size_t)line * 16 + (i & 15u), v);
+    __syncthreads();
+    const bool last = chunk + 1 == chunks || (block_x * chunks + chunk + 1) * kScSamples >= M;
+    if (last || *occupied > kScSlots / 2 - kScSlots / 8) {
+        for (uint32_t i = threadIdx.x; i < kScSlots * 16; i += kScThreads) {
+            const uint32_t line = keys[i >> 4];
+            if (line != kScEmpty) {
+                const float v = vals[i];
+                if (v != 0.0f) atomicAdd(gg + (size_t)line * 16 + (i & 15u), v);
+                if (!last) {                                    // leave an empty table for the next chunk
+                    vals[i] = 0.0f;
+                    if ((i & 15u) == 15u) keys[i >> 4] = kScEmpty;   // the 16 lanes of the slot have read the key above
+                }
+            }
         }
+        if (last) return;
+        __syncthreads();
+        if (threadIdx.x == 0) *occupied = 0u;
+        __syncthreads();
     }
+  }
 }
+
 
 // One launch for the levels of up to two grids that are not binned (the 3-D grid's and the 2-D grid's)
 template <uint32_t D0, uint32_t D1>
@@ -967,9 +990,10 @@ __global__ void __launch_bounds__(kScThreads) k_grid_scatter(ScatterJob j0, Scat
     const uint32_t M = live_count(Mcap, m_dev);
     // two jobs: their workgroups ALTERNATE along x, so that the two grids' work is resident together -- one grid's levels are bound
     // by memory-side atomic requests, the other's by LDS atomics
-    if (n_jobs == 1) scatter_lines<D0>(j0, Mcap, M, keys, vals, blockIdx.x);
-    else if ((blockIdx.x & 1u) == 0) scatter_lines<D0>(j0, Mcap, M, keys, vals, blockIdx.x >> 1);
-    else scatter_lines<D1>(j1, Mcap, M, keys, vals, blockIdx.x >> 1);
+    __shared__ uint32_t occupied;
+    if (n_jobs == 1) scatter_lines<D0>(j0, Mcap, M, keys, vals, &occupied, blockIdx.x);
+    else if ((blockIdx.x & 1u) == 0) scatter_lines<D0>(j0, Mcap, M, keys, vals, &occupied, blockIdx.x >> 1);
+    else scatter_lines<D1>(j1, Mcap, M, keys, vals, &occupied, blockIdx.x >> 1);
 }
 
 // Binned levels.  A level whose gradient table is much larger than what one workgroup's samples touch (the hashed levels of the
@@ -1384,6 +1408,11 @@ static bool scatter_direct_enabled() {
     if (on < 0) { const char *e = getenv("RN_SCATTER_DIRECT"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
+static uint32_t scatter_chunks() {
+    static int n = 0;
+    if (!n) { const char *e = getenv("RN_SCATTER_CHUNKS"); n = e ? atoi(e) : 8; if (n < 1) n = 1; if (n > 16) n = 16; }
+    return (uint32_t)n;
+}
 static ScatterJob make_job(const rn_scatter_job_t &j) {
     ScatterJob s{};
     s.grad = j.grad;
@@ -1481,6 +1510,12 @@ int rn_grid_scatter_jobs(const rn_scatter_job_t *jobs, uint32_t n_jobs, uint32_t
                 direct = gr->gridtype == 0 && stride > rows && rows >= (1u << 17);
             }
             if (direct) sj[i].direct_mask |= 1u << sj[i].n_levels;
+            uint32_t chunks = 1;
+            if (!direct && jobs[i].offsets_host) {
+                const uint32_t rows = (uint32_t)(jobs[i].offsets_host[l + 1] - jobs[i].offsets_host[l]);
+                chunks = rows <= (1u << 16) ? scatter_chunks() : 1u;
+            }
+            sj[i].chunks_of[sj[i].n_levels] = chunks;
             sj[i].level_of[sj[i].n_levels++] = l;
         }
         if (sj[i].n_levels > max_levels) max_levels = sj[i].n_levels;
