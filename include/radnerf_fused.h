@@ -306,6 +306,11 @@ int rn_audio_smooth_seq(const float *enc, uint32_t n, uint32_t dim, float lambda
  * pose: device pointer to a row-major [4,4] (or [3,4]: row stride 4) cam2world matrix. */
 int rn_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
                 float *rays_d, rn_stream_t stream);
+/* get_bg_coords (nerf/utils.py:240-245): bg_coords [H*W, 2] in [-1, 1], component 0 along the image rows.
+ * convert_poses (nerf/utils.py:231-237): n cam2world matrices [n, 4, 4] (row-major) -> poses6 [n, 6] = XYZ euler angles of the
+ * rotation (matrix_to_euler_angles, :130-169) | translation -- the other two inputs of the torso pass, one launch each. */
+int rn_get_bg_coords(uint32_t H, uint32_t W, float *bg_coords, rn_stream_t stream);
+int rn_convert_poses(const float *poses, uint32_t n, float *poses6, rn_stream_t stream);
 
 /* ---- the per-sample MLPs in training --------------------------------------------------------
  * nerf/network.py:69-88 (`MLP`: bias-free nn.Linear stack, ReLU between layers) with its autograd, for the shapes of the

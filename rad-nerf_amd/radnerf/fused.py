@@ -72,6 +72,8 @@ _SIGS = {
     "rn_head_reschedule": [C.POINTER(HeadT), _u32, _u32, _ptr, _ptr],
     "rn_head_check_done": [C.POINTER(HeadT), _u32, _ptr],
     "rn_get_rays": [_ptr, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
+    "rn_get_bg_coords": [_u32, _u32, _ptr, _ptr],
+    "rn_convert_poses": [_ptr, _u32, _ptr, _ptr],
     "rn_torso_pack_weights": [C.POINTER(TorsoWeightsT), _ptr, _ptr],
     "rn_torso_fused": [_ptr, _u32, _ptr, _u32, _f32, _ptr, _ptr, _f32, C.POINTER(TorsoWeightsT), _ptr, C.POINTER(GridT),
                        _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -559,3 +561,18 @@ def get_rays(pose, intrinsics, H, W):
     rays_d = torch.empty(1, H * W, 3, dtype=torch.float32, device=pose.device)
     hip.call("rn_get_rays", hip.ptr(pose), fx, fy, cx, cy, int(H), int(W), hip.ptr(rays_o), hip.ptr(rays_d), hip.stream())
     return {"rays_o": rays_o, "rays_d": rays_d}
+
+
+def get_bg_coords(H, W, device):
+    """[1, H*W, 2] (nerf/utils.py:240-245) in one launch."""
+    out = torch.empty(1, int(H) * int(W), 2, dtype=torch.float32, device=device)
+    hip.call("rn_get_bg_coords", int(H), int(W), hip.ptr(out), hip.stream())
+    return out
+
+
+def convert_poses(poses):
+    """[B, 4, 4] cam2world -> [B, 6] (nerf/utils.py:231-237) in one launch."""
+    p = poses.contiguous().float()
+    out = torch.empty(p.shape[0], 6, dtype=torch.float32, device=p.device)
+    hip.call("rn_convert_poses", hip.ptr(p), p.shape[0], hip.ptr(out), hip.stream())
+    return out

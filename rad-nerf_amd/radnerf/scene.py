@@ -111,13 +111,19 @@ class SyntheticScene:
             poses.append(orbit_pose(self.opt.radius, 8.0 * math.sin(2 * math.pi * t / 4.0),
                                     4.0 * math.sin(2 * math.pi * t / 2.5)))
         self.poses = torch.from_numpy(np.stack(poses)).to(self.device)  # [T,4,4]
-        self.poses6 = convert_poses(self.poses)                        # [T,6]
+        on_device = self.device.type == "cuda" and getattr(self.opt, "engine", "ops") == "fused" and \
+            getattr(self.opt, "ray_engine", "fused") == "fused"
+        if on_device:       # the torso pass's other two inputs, one launch each (rn_convert_poses, rn_get_bg_coords)
+            from . import fused as _fused
+            self.poses6 = _fused.convert_poses(self.poses)
+        else:
+            self.poses6 = convert_poses(self.poses)                    # [T,6]
 
         rng = np.random.default_rng(seed)
         feats = (3.0 * rng.standard_normal((n_frames, 16, 44))).astype(np.float32)
         self.aud_features = torch.from_numpy(feats).permute(0, 2, 1).contiguous().to(self.device)  # [T,44,16]
         self.eye = torch.tensor([[0.25]], dtype=torch.float32, device=self.device)
-        self.bg_coords = get_bg_coords(H, W, self.device)
+        self.bg_coords = _fused.get_bg_coords(H, W, self.device) if on_device else get_bg_coords(H, W, self.device)
         self.bg_color = torch.ones(1, H * W, 3, dtype=torch.float32, device=self.device)
         self._rays = {}
 

@@ -114,3 +114,17 @@ def test_frame_sink_hands_frames_to_pinned_host_memory_and_times_them(hiplib):
     assert sink.pop() is None
     s = timer.summary()
     assert s["frames"] == 4 and 0 < s["p50"] <= s["p95"] and s["fps"] > 0
+
+
+def test_bg_coords_and_pose_vectors_on_the_device(hiplib):
+    """rn_get_bg_coords / rn_convert_poses against the torch mirrors of nerf/utils.py:231-245, which the golden
+    fixture pins to the reference's own functions (tests/test_golden.py)."""
+    import numpy as np
+    from radnerf import fused
+    from radnerf.rays import convert_poses, get_bg_coords, orbit_pose
+    for H, W in ((64, 64), (48, 80), (512, 512)):
+        assert torch.equal(fused.get_bg_coords(H, W, torch.device("cuda")).cpu(), get_bg_coords(H, W, "cpu"))
+    poses = torch.from_numpy(np.stack([orbit_pose(3.35, 8.0 * np.sin(i), 4.0 * np.cos(2 * i)) for i in range(40)])).float()
+    got = fused.convert_poses(poses.cuda()).cpu()
+    assert got.shape == (40, 6)
+    np.testing.assert_allclose(got.numpy(), convert_poses(poses).numpy(), rtol=0, atol=1e-6)

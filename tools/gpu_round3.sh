@@ -36,6 +36,7 @@ RN_SCATTER=binned run bench_train_scatter_binned.json python bench.py --workload
 RN_SCATTER_DIRECT=0 run bench_train_scatter_line_merge_only.json python bench.py --workload train --steps 128
 RN_TRAIN_HEAD=ops RN_TRAIN_LOSS=torch run bench_train_round2_operator_path.json python bench.py --workload train --steps 128
 run bench_hash19_f32_driver_shape.json python bench.py --steps 20 --warmup 5
+run bench_hash19_f32.json python bench.py
 timeout -k 10 400 python tools/train_step_launches.py > "$O/train_step_launches.json" 2> /dev/null || exit 1
 timeout -k 10 120 python tools/bench_train_head.py > "$O/train_head_kernels.json" 2>/dev/null || exit 1
 cd /tmp
