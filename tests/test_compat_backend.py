@@ -180,7 +180,7 @@ def test_all_19_pybind_functions_reproduce_the_reference_vectors(po, hiplib):
     grid = T("occ_grid")
     Cc, H3 = grid.shape
     bitfield = torch.empty(Cc * H3 // 8, dtype=torch.uint8, device=dev)
-    call(rmb, "packbits", grid, Cc * H3, 1.0, bitfield)
+    call(rmb, "packbits", grid, Cc * H3 // 8, 1.0, bitfield)          # N counts OUTPUT bytes (raymarching/raymarching.py:146-152)
     assert np.array_equal(cpu(bitfield), gold["occ_bits"])
     dil = torch.empty_like(grid)
     call(rmb, "morton3D_dilation", grid, Cc, int(round(H3 ** (1 / 3))), dil)
