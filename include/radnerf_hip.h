@@ -166,8 +166,11 @@ int rn_grid_encode_forward(const float *inputs, const void *embeddings, const in
  *   - the first levels -- small, dense -- are done in ONE pass by persistent workgroups that stage the dense ones in LDS
  *     (150 KB of a CU's 160 KB hold levels 0 and 1 of the standard L=16 grids) and gather the next few from L2;
  *   - the remaining levels run level-major (one 4 MB hashed level at a time is what an XCD's L2 holds);
- *   - RN_LAYOUT_BLC: each chunk of samples is computed level-major into `workspace` and transposed to [B, L*C] rows with
- *     16-byte coalesced stores (workspace: rn_grid_encode_forward_workspace() bytes; smaller is allowed, >= 256 samples).
+ *   - RN_LAYOUT_BLC: each chunk of samples is computed level-major into `workspace` and its [B, L*C] rows are written by
+ *     the launch of the first of those levels, which runs last and moves the other levels' slabs along with its own gathers
+ *     (rows of <= 128 bytes; wider rows: one 128-byte segment per launch of the last levels; other shapes: a transposition
+ *     pass).  16-byte coalesced stores (workspace: rn_grid_encode_forward_workspace() bytes; smaller is allowed, >= 256
+ *     samples).
  * Any other shape (or offsets_host == NULL) takes rn_grid_encode_forward.  Results are bit-identical either way. */
 size_t rn_grid_encode_forward_workspace(uint32_t B, uint32_t L, uint32_t C, int dtype);
 int rn_grid_encode_forward_ws(const float *inputs, const void *embeddings, const int32_t *offsets,
@@ -175,6 +178,17 @@ int rn_grid_encode_forward_ws(const float *inputs, const void *embeddings, const
                               uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
                               uint32_t interp, int dtype, int layout, void *workspace, size_t workspace_bytes,
                               rn_stream_t stream);
+/* GridEncoder.forward without its pass over the coordinates (gridencoder/grid.py:145-163): takes world coordinates in
+ * [-bound, bound] and applies `inputs = (inputs + bound) / (2 * bound)` (grid.py:149) inside the lookup's coordinate load --
+ * as (x + bound) * (1 / (2 bound)), both in fp32: what that line computes on the device, where PyTorch turns the division by
+ * a host scalar into a multiplication by its fp32 reciprocal (identical to the division whenever 2 * bound is a power of
+ * two, e.g. the reference's bound = 1).  Planned shapes only (see rn_grid_encode_forward_ws: offsets_host given, D in {2,3},
+ * C in {2,4}, no dy_dx, align_corners off, linear interpolation); anything else returns RN_ERR_INVALID_ARG.
+ * With RN_LAYOUT_BLC the [B, L*C] rows are written by the last level launch itself (no transposition pass). */
+int rn_grid_encode_forward_bound(const float *inputs, float bound, const void *embeddings, const int32_t *offsets,
+                                 const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                 float S, uint32_t H, uint32_t gridtype, int dtype, int layout, void *workspace,
+                                 size_t workspace_bytes, rn_stream_t stream);
 /* gridencoder.h:13  grid_encode_backward    (gridencoder.cu:247-368, 401-443, 472-502)
  * grad_embeddings must be zero-initialised (grid.py:77); grad_inputs may be NULL. */
 int rn_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,

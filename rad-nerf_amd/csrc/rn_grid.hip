@@ -22,12 +22,19 @@
 
 namespace rn {
 
+// GridEncoder.forward's `inputs = (inputs + bound) / (2 * bound)` (gridencoder/grid.py:149) folded into the lookup's coordinate
+// load: x -> (x + add) * mul with mul = 1 / (2 * bound) in fp32 -- what the division by a host scalar computes on the device
+// in PyTorch -- so the module needs no pass of its own over the coordinates.  on = 0: coordinates are used as given.
+struct InXform { float add, mul; uint32_t on; };
+
 template <uint32_t D>
-__device__ __forceinline__ bool load_input(const float *__restrict__ inputs, uint32_t b, float (&in)[D]) {
+__device__ __forceinline__ bool load_input(const float *__restrict__ inputs, uint32_t b, float (&in)[D], const InXform xf = InXform{0, 1, 0}) {
     bool oob = false;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        in[d] = inputs[(size_t)b * D + d];
+        float x = inputs[(size_t)b * D + d];
+        if (xf.on) x = (x + xf.add) * xf.mul;
+        in[d] = x;
         oob |= (in[d] < 0 || in[d] > 1);  // gridencoder.cu:113-117
     }
     return oob;
@@ -58,13 +65,14 @@ template <typename T, uint32_t D, uint32_t C, bool DYDX, int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_grid_fwd_level(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
                  T *__restrict__ outputs, uint32_t B, uint32_t L, LevelConsts lc, T *__restrict__ dy_dx,
-                 uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t level_base) {
+                 uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t level_base, uint32_t level_skip, InXform xf) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    const uint32_t level = blockIdx.y + level_base;   // level_base > 0: the coarse levels were done by k_grid_fwd_coarse
+    uint32_t level = blockIdx.y + level_base;         // level_base > 0: the coarse levels were done by k_grid_fwd_coarse
+    level += level >= level_skip ? 1u : 0u;           // level_skip < L: that level is another launch's (k_grid_fwd_level_rows)
 
     float in[D];
-    const bool oob = load_input<D>(inputs, b, in);
+    const bool oob = load_input<D>(inputs, b, in, xf);
 
     T results[C];
     T grads[DYDX ? D * C : 1];
@@ -149,7 +157,7 @@ template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kCoarseThreads)
 k_grid_fwd_coarse(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
                   T *__restrict__ outputs, uint32_t B, LevelConsts lc, uint32_t gridtype, uint32_t n_lds, uint32_t n_group,
-                  uint32_t lds_bytes) {
+                  uint32_t lds_bytes, InXform xf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_rows[];
     __shared__ LevelPlan plans[kCoarseMaxLevels];
     for (uint32_t i = threadIdx.x * 16u; i < lds_bytes; i += kCoarseThreads * 16u)   // level sizes are multiples of 8 rows: 16-B chunks
@@ -164,7 +172,7 @@ k_grid_fwd_coarse(const float *__restrict__ inputs, const T *__restrict__ table,
         const uint32_t b = tile * kCoarseThreads + threadIdx.x;
         if (b >= B) continue;
         float in[D];
-        const bool oob = load_input<D>(inputs, b, in);
+        const bool oob = load_input<D>(inputs, b, in, xf);
         T dummy[1];
         if (oob) {
             T zero[C];
@@ -249,6 +257,98 @@ k_grid_lbc_to_blc(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, 
         for (uint32_t q = threadIdx.x; q < total; q += kTrThreads) {
             const uint32_t s = q / row_words, k = q - s * row_words;
             out[q] = tile[s * stride + k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A fine level's pass that ALSO moves NT finished levels of the chunk to their place in the [B, L*C] rows, so the module's
+// layout needs no transposition pass of its own.  Why here: a hashed level's kernel waits for its 8 gathers per sample and
+// leaves most of the memory pipes idle, so the coalesced reads of the other levels' slabs and the row stores ride along --
+// the 2 x 0.5 GB that `k_grid_lbc_to_blc` streams in 205 us at B = 2^22 cost 140 us more than the level alone when they
+// travel with level 5 (the first fine level of the T = 2^19 table: the cheapest gathers; 180 us with level 15).
+// A launch has a duty of NT levels [t0, t0 + NT), all complete when it runs except possibly its own (slot `own`, taken from
+// registers); per sample it writes one aligned segment of NT * C * sizeof(T) bytes: the whole row (<= 128 B) or a 128-byte
+// line of it.  Segments smaller than a line were measured and are slower than the transposition pass (two 64-byte halves
+// written 100 us apart: 1.03 ms against 0.95), so the LDS tile holds 128 samples x whole segments at a time (two passes,
+// <= 20 KB: 7-8 workgroups per CU) rather than 256 samples x half segments.
+// Same plan / issue / blend as k_grid_fwd_level: bit-identical features.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <uint32_t W>
+__device__ __forceinline__ void load_words_nt(const uint32_t *p, uint32_t (&v)[W]) {
+    if constexpr (W == 1) v[0] = __builtin_nontemporal_load(p);
+    else if constexpr (W == 2) { const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)); v[0] = t.x; v[1] = t.y; }
+    else { static_assert(W == 4, "rows of 1, 2 or 4 words");
+           const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+
+template <typename T, uint32_t D, uint32_t C, uint32_t NT>
+__global__ void __launch_bounds__(256)
+k_grid_fwd_level_rows(const float *__restrict__ inputs, const T *__restrict__ table, const int32_t *__restrict__ offsets,
+                      T *__restrict__ ws /* [L, B, C] */, uint32_t *__restrict__ rows /* [B, L * C] as words */, uint32_t B, uint32_t L,
+                      LevelConsts lc, uint32_t gridtype, uint32_t level, uint32_t t0, uint32_t own /* level - t0, or >= NT */, InXform xf) {
+    constexpr uint32_t W = (uint32_t)(sizeof(T) * C / 4);     // words per (sample, level)
+    constexpr uint32_t SEG = NT * W, STRIDE = SEG + 4u;       // words per sample moved here; padded LDS row (stays 16-byte aligned)
+    constexpr uint32_t SP = SEG > 16u ? 128u : 256u;          // samples per LDS pass: <= 20 KB per workgroup keeps 8 of them on a CU
+    static_assert(SEG % 4 == 0, "a sample's segment is whole 16-byte quads");
+    __shared__ __attribute__((aligned(16))) uint32_t tile[SP * STRIDE];
+    const uint32_t s0 = blockIdx.x * 256u, b = s0 + threadIdx.x;
+    const bool have = b < B;
+    float in[D];
+    bool oob = true;
+    if (have) oob = load_input<D>(inputs, b, in, xf);
+    const uint32_t off = (uint32_t)offsets[level];
+    const LevelPlan lp = plan_level<D>(lc.scale[level], lc.resolution[level], off, (uint32_t)offsets[level + 1] - off, gridtype,
+                                       (uint32_t)(sizeof(T) * C));
+    LevelFetch<T, D, C> f;
+    if (!oob) issue_planned<T, D, C, RN_GRID_PAIR_HASHED != 0, true>(table, lp, in, f);   // this level's gathers: in flight first
+    uint32_t v[NT][W];
+    const uint32_t *slab = reinterpret_cast<const uint32_t *>(ws);
+#pragma unroll
+    for (uint32_t j = 0; j < NT; j++) {
+        if (have) load_words_nt<W>(slab + ((size_t)(t0 + j) * B + b) * W, v[j]);   // (the own level's slot too: stale words, replaced below)
+        else {
+#pragma unroll
+            for (uint32_t i = 0; i < W; i++) v[j][i] = 0u;
+        }
+    }
+    T res[C], dummy[1];
+    if (oob) {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) res[ch] = from_f<T>(0.0f);
+    } else {
+        blend_level<T, D, C, false>(f, 0.0f, res, dummy);
+    }
+    uint32_t own_words[W];
+    __builtin_memcpy(own_words, res, sizeof(T) * C);
+    if (own >= NT && have) store_row_nt<T, C>(ws + ((size_t)level * B + b) * C, res);   // a later launch's duty
+    constexpr uint32_t QS = SEG / 4u;                         // 16-byte quads per sample
+    const uint32_t n_all = B - s0 < 256u ? B - s0 : 256u;
+    const size_t row_words = (size_t)L * W;
+#pragma unroll
+    for (uint32_t pass = 0; pass < 256u / SP; pass++) {
+        if (pass) __syncthreads();                            // the previous pass's rows have left the tile
+        if (threadIdx.x / SP == pass) {
+            uint32_t *mine = tile + (threadIdx.x - pass * SP) * STRIDE;
+#pragma unroll
+            for (uint32_t j = 0; j < NT; j++) {
+#pragma unroll
+                for (uint32_t i = 0; i < W; i++) mine[j * W + i] = v[j][i];
+            }
+            if (own < NT) {                                       // this launch's own level sits in its duty: from registers
+#pragma unroll
+                for (uint32_t i = 0; i < W; i++) mine[own * W + i] = own_words[i];
+            }
+        }
+        __syncthreads();
+        const uint32_t first = pass * SP;
+        const uint32_t n = n_all > first ? (n_all - first < SP ? n_all - first : SP) : 0u;
+        for (uint32_t q = threadIdx.x; q < n * QS; q += 256u) {
+            const uint32_t s = q / QS, k = q - s * QS;
+            const u32x4 val = *reinterpret_cast<const u32x4 *>(tile + s * STRIDE + 4u * k);
+            __builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(rows + (size_t)(s0 + first + s) * row_words + (size_t)t0 * W + 4u * k));
         }
     }
 }
@@ -581,10 +681,10 @@ static void launch_fwd(const FwdArgs &a) {
                        a.L, a.lc, dy, a.gridtype, a.align_corners, a.interp, ##__VA_ARGS__)
     if (a.layout == RN_LAYOUT_LBC) {
         const dim3 grid(div_up(a.B, 256), a.L);
-        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_LBC, 0u); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_LBC, 0u);
+        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_LBC, 0u, ~0u, InXform{0, 1, 0}); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_LBC, 0u, ~0u, InXform{0, 1, 0});
     } else if (a.layout == RN_LAYOUT_BLC_LEVELMAJOR) {
         const dim3 grid(div_up(a.B, 256), a.L);
-        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_BLC, 0u); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_BLC, 0u);
+        if (dy) RN_FWD(k_grid_fwd_level, grid, true, RN_LAYOUT_BLC, 0u, ~0u, InXform{0, 1, 0}); else RN_FWD(k_grid_fwd_level, grid, false, RN_LAYOUT_BLC, 0u, ~0u, InXform{0, 1, 0});
     } else {
         const dim3 grid(div_up(a.B, 256));
         if (dy) RN_FWD(k_grid_fwd_sample, grid, true, RN_LAYOUT_BLC); else RN_FWD(k_grid_fwd_sample, grid, false, RN_LAYOUT_BLC);
@@ -670,7 +770,8 @@ static CoarseSplit coarse_split(const int32_t *oh, uint32_t L, const LevelConsts
 // [L, Bc, C] for samples of one chunk
 template <typename T, uint32_t D, uint32_t C>
 static void launch_planned_lbc(const float *inputs, const T *table, const int32_t *offsets, const int32_t *oh, T *out, uint32_t Bc,
-                               uint32_t L, const LevelConsts &lc, uint32_t gridtype, hipStream_t s) {
+                               uint32_t L, const LevelConsts &lc, uint32_t gridtype, const InXform &xf, hipStream_t s, uint32_t skip_last = 0,
+                               uint32_t skip_level = ~0u) {
     const CoarseSplit cs = coarse_split<T, D, C>(oh, L, lc, gridtype, Bc);
     if (cs.n_group) {
         static bool attr_set = false;
@@ -683,12 +784,67 @@ static void launch_planned_lbc(const float *inputs, const T *table, const int32_
         const uint32_t cap = (uint32_t)grid_cus();       // one persistent workgroup per CU (its LDS holds the staged levels)
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL((k_grid_fwd_coarse<T, D, C>), dim3(blocks), dim3(kCoarseThreads), cs.lds_bytes, s, inputs, table, offsets,
-                           out, Bc, lc, gridtype, cs.n_lds, cs.n_group, cs.lds_bytes);
+                           out, Bc, lc, gridtype, cs.n_lds, cs.n_group, cs.lds_bytes, xf);
     }
-    if (cs.n_group < L) {
-        const dim3 grid(div_up(Bc, 256), L - cs.n_group);
+    // skip_last / skip_level: levels the caller launches itself (launch_planned_rows)
+    uint32_t n_fine = L - skip_last - cs.n_group;
+    if (skip_level >= cs.n_group && skip_level < L - skip_last) n_fine--;
+    else skip_level = ~0u;
+    if (cs.n_group < L - skip_last && n_fine) {
+        const dim3 grid(div_up(Bc, 256), n_fine);
         hipLaunchKernelGGL((k_grid_fwd_level<T, D, C, false, RN_LAYOUT_LBC>), grid, dim3(256), 0, s, inputs, table, offsets, out, Bc, L,
-                           lc, static_cast<T *>(nullptr), gridtype, false, 0u, cs.n_group);
+                           lc, static_cast<T *>(nullptr), gridtype, false, 0u, cs.n_group, skip_level, xf);
+    }
+}
+
+// [B, L*C] without a transposition pass (k_grid_fwd_level_rows): which launches carry a duty, and how many levels each.
+// n_seg = 0: not this shape -> transposition kernel.  One segment (rows of <= 128 bytes: every L = 16, C = 2 grid): the duty
+// goes to the FIRST fine level, launched last -- the cheapest gathers leave the most room for the streams (measured at
+// B = 2^22, hash T = 2^19, same box: transposition pass 0.968 ms, duty on level 15: 0.926, on level 5: 0.884).  Rows wider
+// than a line are split into 128-byte segments over the last n_seg levels, in level order.
+struct RowsPlan { uint32_t n_seg, nt, own_level; };
+
+template <typename T, uint32_t D, uint32_t C>
+static RowsPlan rows_plan(const int32_t *oh, uint32_t L, const LevelConsts &lc, uint32_t gridtype, uint32_t Bc) {
+    const char *off = getenv("RN_GRID_ROWS");                        // "0": keep the transposition pass (tests toggle it: read per call)
+    static const char *segs = getenv("RN_GRID_ROWS_SEGS");           // experiments only
+    static const char *own_env = getenv("RN_GRID_ROWS_OWN");         // experiments only: the level that carries a one-segment duty
+    const RowsPlan none{0, 0, 0};
+    if (off && off[0] == '0') return none;
+    constexpr uint32_t W = (uint32_t)(sizeof(T) * C / 4);
+    const uint32_t row_bytes = L * W * 4u;
+    uint32_t n_seg = (row_bytes + 127u) / 128u;                      // a launch writes whole 128-byte lines (or the whole row)
+    if (segs) n_seg = (uint32_t)atoi(segs);
+    if (n_seg < 1u || L % n_seg) return none;
+    const uint32_t nt = L / n_seg;
+    if ((nt != 4u && nt != 8u && nt != 16u) || (nt * W) % 4u || nt * W > 32u) return none;
+    const CoarseSplit cs = coarse_split<T, D, C>(oh, L, lc, gridtype, Bc);
+    if (L - cs.n_group < n_seg) return none;                         // the duty levels must come after everything they move
+    uint32_t own = n_seg == 1u ? cs.n_group : 0u;
+    if (own_env && n_seg == 1u && (uint32_t)atoi(own_env) >= cs.n_group && (uint32_t)atoi(own_env) < L) own = (uint32_t)atoi(own_env);
+    return RowsPlan{n_seg, nt, own};
+}
+
+template <typename T, uint32_t D, uint32_t C, uint32_t NT>
+static void launch_rows_nt(const float *inputs, const T *table, const int32_t *offsets, T *ws, void *rows, uint32_t Bc, uint32_t L,
+                           const LevelConsts &lc, uint32_t gridtype, uint32_t level, uint32_t t0, const InXform &xf, hipStream_t s) {
+    const uint32_t own = (level >= t0 && level - t0 < NT) ? level - t0 : NT;
+    hipLaunchKernelGGL((k_grid_fwd_level_rows<T, D, C, NT>), dim3(div_up(Bc, 256)), dim3(256), 0, s, inputs, table, offsets, ws,
+                       static_cast<uint32_t *>(rows), Bc, L, lc, gridtype, level, t0, own, xf);
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static void launch_planned_rows(const RowsPlan &rp, const float *inputs, const T *table, const int32_t *offsets, const int32_t *oh, T *ws,
+                                void *rows, uint32_t Bc, uint32_t L, const LevelConsts &lc, uint32_t gridtype, const InXform &xf,
+                                hipStream_t s) {
+    if (rp.n_seg == 1) launch_planned_lbc<T, D, C>(inputs, table, offsets, oh, ws, Bc, L, lc, gridtype, xf, s, 0, rp.own_level);
+    else launch_planned_lbc<T, D, C>(inputs, table, offsets, oh, ws, Bc, L, lc, gridtype, xf, s, rp.n_seg);
+    for (uint32_t i = 0; i < rp.n_seg; i++) {
+        const uint32_t level = rp.n_seg == 1 ? rp.own_level : L - rp.n_seg + i, t0 = i * rp.nt;
+        if (rp.nt == 4) launch_rows_nt<T, D, C, 4>(inputs, table, offsets, ws, rows, Bc, L, lc, gridtype, level, t0, xf, s);
+        else if (rp.nt == 8) launch_rows_nt<T, D, C, 8>(inputs, table, offsets, ws, rows, Bc, L, lc, gridtype, level, t0, xf, s);
+        else if constexpr (16u * sizeof(T) * C / 4u <= 32u)
+            launch_rows_nt<T, D, C, 16>(inputs, table, offsets, ws, rows, Bc, L, lc, gridtype, level, t0, xf, s);
     }
 }
 
@@ -712,7 +868,7 @@ static void launch_transpose(const void *src, void *dst, uint32_t Bc, uint32_t L
 
 struct PlannedArgs {
     const float *inputs; const void *table; const int32_t *offsets, *offsets_host; void *outputs; uint32_t B, L; LevelConsts lc;
-    uint32_t gridtype; int layout; void *ws; size_t ws_bytes; hipStream_t stream;
+    uint32_t gridtype; int layout; void *ws; size_t ws_bytes; hipStream_t stream; InXform xf;
 };
 
 static uint32_t planned_chunk_default() {
@@ -730,7 +886,7 @@ static int run_planned(const PlannedArgs &a) {
     const T *table = static_cast<const T *>(a.table);
     if (a.layout == RN_LAYOUT_LBC) {
         launch_planned_lbc<T, D, C>(a.inputs, table, a.offsets, a.offsets_host, static_cast<T *>(a.outputs), a.B, a.L, a.lc, a.gridtype,
-                                    a.stream);
+                                    a.xf, a.stream);
         return RN_OK;
     }
     constexpr uint32_t kRowBytes = sizeof(T) * C;
@@ -744,9 +900,16 @@ static int run_planned(const PlannedArgs &a) {
                per_sample);
     for (size_t b0 = 0; b0 < a.B; b0 += chunk) {
         const uint32_t Bc = (uint32_t)((a.B - b0) < chunk ? (a.B - b0) : chunk);
+        void *rows = static_cast<char *>(a.outputs) + b0 * per_sample;
+        const RowsPlan rp = rows_plan<T, D, C>(a.offsets_host, a.L, a.lc, a.gridtype, Bc);
+        if (rp.n_seg) {
+            launch_planned_rows<T, D, C>(rp, a.inputs + b0 * D, table, a.offsets, a.offsets_host, static_cast<T *>(a.ws), rows, Bc, a.L,
+                                         a.lc, a.gridtype, a.xf, a.stream);
+            continue;
+        }
         launch_planned_lbc<T, D, C>(a.inputs + b0 * D, table, a.offsets, a.offsets_host, static_cast<T *>(a.ws), Bc, a.L, a.lc, a.gridtype,
-                                    a.stream);
-        launch_transpose<kRowBytes / 4>(a.ws, static_cast<char *>(a.outputs) + b0 * per_sample, Bc, a.L, a.stream);
+                                    a.xf, a.stream);
+        launch_transpose<kRowBytes / 4>(a.ws, rows, Bc, a.L, a.stream);
     }
     return RN_OK;
 }
@@ -863,26 +1026,46 @@ size_t rn_grid_encode_forward_workspace(uint32_t B, uint32_t L, uint32_t C, int 
     return chunk * per_sample;
 }
 
-int rn_grid_encode_forward_ws(const float *inputs, const void *embeddings, const int32_t *offsets, const int32_t *offsets_host,
-                              void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
-                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int layout, void *workspace,
-                              size_t workspace_bytes, rn_stream_t stream) {
+static int grid_forward_ws(const float *inputs, const void *embeddings, const int32_t *offsets, const int32_t *offsets_host,
+                           void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
+                           uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int layout, void *workspace,
+                           size_t workspace_bytes, const InXform &xf, rn_stream_t stream, const char *who) {
     if (B == 0) return RN_OK;
-    RN_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward_ws: null pointer");
-    RN_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward_ws: L=%u out of range (1..%u)", L, kMaxLevels);
-    RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "grid_encode_forward_ws: dtype must be RN_F32 or RN_F16");
-    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "grid_encode_forward_ws: layout must be RN_LAYOUT_LBC or RN_LAYOUT_BLC");
+    RN_REQUIRE(inputs && embeddings && offsets && outputs, "%s: null pointer", who);
+    RN_REQUIRE(L >= 1 && L <= kMaxLevels, "%s: L=%u out of range (1..%u)", who, L, kMaxLevels);
+    RN_REQUIRE(dtype == RN_F32 || dtype == RN_F16, "%s: dtype must be RN_F32 or RN_F16", who);
+    RN_REQUIRE(layout == RN_LAYOUT_LBC || layout == RN_LAYOUT_BLC, "%s: layout must be RN_LAYOUT_LBC or RN_LAYOUT_BLC", who);
     const bool shape_ok = offsets_host && !dy_dx && !align_corners && interp == 0 && (D == 2 || D == 3) && (C == 2 || C == 4) &&
                           ((uintptr_t)embeddings & 15u) == 0 && ((uintptr_t)outputs & 15u) == 0 &&
                           (layout == RN_LAYOUT_LBC || (workspace && ((uintptr_t)workspace & 15u) == 0));
     if (shape_ok) {
         PlannedArgs a{inputs, embeddings, offsets, offsets_host, outputs, B, L, make_level_consts(L, S, H), gridtype, layout, workspace,
-                      workspace_bytes, as_stream(stream)};
+                      workspace_bytes, as_stream(stream), xf};
         const int rc = (dtype == RN_F32) ? dispatch_planned<float>(D, C, a) : dispatch_planned<__half>(D, C, a);
-        if (rc <= 0) return rc != RN_OK ? rc : check_launch("grid_encode_forward_ws");
+        if (rc <= 0) return rc != RN_OK ? rc : check_launch(who);
     }
+    RN_REQUIRE(!xf.on, "%s: only the planned shapes (offsets_host given, D in {2,3}, C in {2,4}, 16-byte aligned buffers); normalise the "
+               "coordinates yourself and call rn_grid_encode_forward_ws", who);
     return rn_grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype,
                                   layout, stream);
+}
+
+int rn_grid_encode_forward_ws(const float *inputs, const void *embeddings, const int32_t *offsets, const int32_t *offsets_host,
+                              void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
+                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int layout, void *workspace,
+                              size_t workspace_bytes, rn_stream_t stream) {
+    return grid_forward_ws(inputs, embeddings, offsets, offsets_host, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
+                           dtype, layout, workspace, workspace_bytes, InXform{0.0f, 1.0f, 0u}, stream, "grid_encode_forward_ws");
+}
+
+int rn_grid_encode_forward_bound(const float *inputs, float bound, const void *embeddings, const int32_t *offsets,
+                                 const int32_t *offsets_host, void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                 uint32_t H, uint32_t gridtype, int dtype, int layout, void *workspace, size_t workspace_bytes,
+                                 rn_stream_t stream) {
+    RN_REQUIRE(bound > 0.0f, "grid_encode_forward_bound: bound must be positive");
+    const float denom = 2.0f * bound;
+    return grid_forward_ws(inputs, embeddings, offsets, offsets_host, outputs, B, D, C, L, S, H, nullptr, gridtype, 0, 0u, dtype, layout,
+                           workspace, workspace_bytes, InXform{bound, 1.0f / denom, 1u}, stream, "grid_encode_forward_bound");
 }
 
 int rn_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,

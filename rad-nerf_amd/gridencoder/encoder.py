@@ -156,8 +156,35 @@ class GridEncoder(nn.Module):
             self._half = (key, e.detach().to(torch.half))
         return self._half[1]
 
+    def _lookup_only(self, inputs, bound):
+        """No gradient wanted by anybody: one library call, the normalisation of grid.py:149 folded into the lookup's coordinate
+        load (rn_grid_encode_forward_bound) -- no pass over the coordinates, nothing saved for a backward pass."""
+        D, C, L = self.input_dim, self.level_dim, self.num_levels
+        prefix_shape = list(inputs.shape[:-1])
+        x = hip.dev(inputs).reshape(-1, D)
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        B = x.shape[0]
+        if torch.is_autocast_enabled("cuda") and C % 2 == 0:
+            table = self.half_table()
+        else:
+            table = hip.aligned(self.embeddings.detach())
+        outputs = torch.empty(B, L * C, device=x.device, dtype=table.dtype)
+        if B:
+            ws = hip.grid_forward_workspace(B, L, C, _dtype_id(table), x.device)
+            hip.call("rn_grid_encode_forward_bound", hip.ptr(x), float(bound), hip.ptr(table), hip.ptr(self.offsets, torch.int32),
+                     hip.host_offsets(self.offsets), hip.ptr(outputs), B, D, C, L, float(np.log2(self.per_level_scale)),
+                     int(self.base_resolution), self.gridtype_id, _dtype_id(table), hip.RN_LAYOUT_BLC, hip.ptr(ws), ws.numel(),
+                     hip.stream())
+        return outputs.view(prefix_shape + [self.output_dim])
+
     def forward(self, inputs, bound=1):
         # inputs: [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
+        wants_grad = torch.is_grad_enabled() and (inputs.requires_grad or self.embeddings.requires_grad)
+        if (not wants_grad and inputs.is_cuda and self.input_dim in (2, 3) and self.level_dim in (2, 4)
+                and not self.align_corners and self.interp_id == 0):
+            return self._lookup_only(inputs, bound)
         inputs = (inputs + bound) / (2 * bound)
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)

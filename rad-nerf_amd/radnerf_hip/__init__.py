@@ -48,6 +48,8 @@ _SIGNATURES = {
                                _i32, _i32, _ptr],
     "rn_grid_encode_forward_ws": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _i32, _u32,
                                   _i32, _i32, _ptr, _sz, _ptr],
+    "rn_grid_encode_forward_bound": [_ptr, _f32, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32,
+                                     _ptr, _sz, _ptr],
     "rn_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr,
                                 _u32, _i32, _u32, _i32, _i32, _ptr],
     "rn_grad_total_variation": [_ptr, _ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32,

@@ -397,6 +397,39 @@ def test_grid_encoder_module_uses_planned_path_and_matches_oracle(po, hiplib, rn
     assert np.array_equal(y.cpu().numpy(), e_out.transpose(1, 0, 2).reshape(B, -1))
 
 
+@pytest.mark.parametrize("gridtype,log2T", [("hash", 19), ("tiled", 16)])
+def test_grid_encoder_module_folds_the_bound_and_writes_rows_without_a_transposition(hiplib, gridtype, log2T):
+    """GridEncoder.forward with no gradient wanted = ONE library call (rn_grid_encode_forward_bound: grid.py:149's normalisation
+    inside the coordinate load, [B, L*C] rows written by the last level launch).  Bit-identical to (a) the autograd path, which
+    normalises with torch ops as the reference does, for bounds whose doubles are and are not powers of two, and (b) the same
+    call with the transposition pass (RN_GRID_ROWS=0), fp32 and fp16 tables."""
+    import os
+    from gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=log2T, desired_resolution=2048,
+                      gridtype=gridtype).cuda()
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    B = 70001
+    for bound in (1, 2, 1.5, 0.7):
+        x = (torch.rand(B, 3, device=DEV) * 2.2 - 1.1) * bound     # some points outside [-bound, bound]
+        with torch.no_grad():
+            fast = enc(x, bound=bound)
+        slow = enc(x, bound=bound)                                # embeddings.requires_grad: torch normalisation + autograd Function
+        assert slow.requires_grad and not fast.requires_grad
+        assert torch.equal(fast, slow.detach()), bound
+        os.environ["RN_GRID_ROWS"] = "0"
+        try:
+            with torch.no_grad():
+                transposed = enc(x, bound=bound)
+                with torch.autocast("cuda", dtype=torch.half):
+                    transposed_h = enc(x, bound=bound)
+        finally:
+            del os.environ["RN_GRID_ROWS"]
+        assert torch.equal(fast, transposed), bound
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.half):
+            fast_h = enc(x, bound=bound)
+        assert fast_h.dtype == torch.half and torch.equal(fast_h, transposed_h), bound
+
+
 @pytest.mark.parametrize("D,C,L,log2T,gridtype,B", [c for c in GRID_CASES if c[1] % 2 == 0][:4])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_grid_forward_fp16_bit_exact(po, hiplib, rng, D, C, L, log2T, gridtype, B, layout):

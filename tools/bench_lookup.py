@@ -12,7 +12,7 @@ points: "frame"   = what the marcher emits for consecutive 512^2 frames of the b
         "uniform" = i.i.d. uniform points (no coherence at all).
 layouts: lbc / blc = rn_grid_encode_forward_ws ([L,B,C]: the reference kernel's layout, what compat_backend calls; [B,L*C]:
          what GridEncoder.forward calls); lbc0 / blc0 = round 1's rn_grid_encode_forward (per-level / sample-major kernel);
-         module = gridencoder.GridEncoder.forward (the operator surface: includes its input scaling pass).
+         module = gridencoder.GridEncoder.forward (the operator surface; since round 3 its input scaling is folded into the lookup).
 Timing: HIP events around each call on torch's current stream, median of --rounds; run under
 `rocprofv3 --kernel-trace --stats` (tools/gpu_lookup_profile.sh) for the profiler's view of the same launches."""
 import argparse
