@@ -91,6 +91,14 @@ def _train_scene(device):
     return SyntheticScene(H=256, W=256, n_frames=8, device=device, opt=default_opt(torso=False, smooth_lips=False, engine="ops"))
 
 
+def _reference_inputs(device):
+    """Frame 0 of the training scene built on the CPU -- bit for bit the rays the generator handed to the reference -- then moved.
+    (Rays built by the same torch code ON the GPU differ from these in the last bit of rays_d; through the finest grid levels
+    that is 2e-4 in enc_x and 3e-3 in enc_w: tools/debug_smooth_samples.py.)"""
+    f = _train_scene("cpu").frame(0)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in f.items()}
+
+
 def test_oracle_train_branch_matches_reference(po, gold, hiplib):
     """renderer.py:183-223, 306-311 restated over the oracle operators: near/far on aabb_train -> march_rays_train -> network
     -> composite_rays_train -> blend."""
@@ -145,12 +153,14 @@ def test_hip_config0_frame_matches_reference(gold, hiplib, engine):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("head", ["fused", "ops"])
 @pytest.mark.parametrize("tag,mean_count", [("first", 0), ("steady", 49152)])
-def test_hip_train_branch_matches_reference(gold, hiplib, tag, mean_count):
+def test_hip_train_branch_matches_reference(gold, hiplib, monkeypatch, tag, mean_count, head):
+    monkeypatch.setenv("RN_TRAIN_HEAD", head)         # the fused forward / backward kernels, and the per-operator chain
     scene = _train_scene("cuda")
     m, opt = scene.model, scene.opt
     m.train()
-    f = scene.frame(0)
+    f = _reference_inputs("cuda")
     px = torch.from_numpy(gold["train_px"]).cuda()
     m.zero_grad(set_to_none=True)
     m.mean_count, m.local_step = mean_count, 0
@@ -164,32 +174,118 @@ def test_hip_train_branch_matches_reference(gold, hiplib, tag, mean_count):
     loss.backward()
     n = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
     assert np.array_equal(n(m.step_counter[0]).astype(np.int32), gold[f"train_{tag}_counter"])
-    np.testing.assert_allclose(n(res["weights_sum"]), gold[f"train_{tag}_weights_sum"], rtol=0, atol=3e-5)
-    np.testing.assert_allclose(n(res["ambient"]), gold[f"train_{tag}_ambient"], rtol=0, atol=2e-4)
-    _check_frame(n(res["image"]).reshape(-1, 3), n(res["depth"]).reshape(-1), gold, f"train_{tag}", 5e-5, 2e-4)
-    assert abs(float(loss) - float(gold[f"train_{tag}_loss"])) <= 2e-3 * abs(float(gold[f"train_{tag}_loss"]))
+    # the inputs are the reference's, bit for bit (_reference_inputs), so the marcher's samples and enc_x are too, and the
+    # outputs agree to fp32 rounding: achieved 1.5e-7 (weights_sum), 1.2e-7 (ambient), 1.8e-7 (image)
+    np.testing.assert_allclose(n(res["weights_sum"]), gold[f"train_{tag}_weights_sum"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(n(res["ambient"]), gold[f"train_{tag}_ambient"], rtol=0, atol=2e-6)
+    _check_frame(n(res["image"]).reshape(-1, 3), n(res["depth"]).reshape(-1), gold, f"train_{tag}", 2e-6, 2e-4)
+    assert abs(float(loss) - float(gold[f"train_{tag}_loss"])) <= 2e-5 * abs(float(gold[f"train_{tag}_loss"]))
     params = dict(m.named_parameters())
-    # Parameters downstream of the ambient grid see sums over ~45 k samples in another order (rocBLAS split-K weight-gradient
-    # GEMMs, atomics): 5e-3 of the largest entry.  Parameters UPSTREAM of it (ambient_net, and the audio nets through enc_a) get
-    # their gradient through d(grid)/d(coordinate), which is piecewise constant: a coordinate that differs in its last bits
-    # lands in the neighbouring cell of a fine level and that sample's term changes by O(1) -- the sum is only stable to ~2 %.
+    # Parameters downstream of the ambient grid: sums over ~45 k samples in another order -- achieved 2.4e-6 of the largest
+    # entry, bar 5e-5.  Parameters UPSTREAM of it (ambient_net, and the audio nets through enc_a) get their gradient through
+    # d(grid)/d(coordinate), which is piecewise constant: a coordinate that differs in its last bits (1.6e-8 here) can land in the
+    # neighbouring cell of a fine level and that sample's term changes by O(1).  A handful of samples do: achieved 5e-4 (fused
+    # training pass) / 1.3e-3 (per-operator chain), bar 5e-3.  test_hip_train_branch_gradients_on_smooth_samples removes those
+    # samples and holds the same parameters to 1e-4.
     for key in gold.files:
         if key.startswith(f"train_{tag}_grad::"):
             name = key.split("::")[1]
             got = n(params[name].grad if name != "individual_codes" else params[name].grad[:1])
             want = gold[key]
-            tol = 3e-2 if name.startswith(("ambient_net", "audio_")) else 5e-3
+            tol = 5e-3 if name.startswith(("ambient_net", "audio_")) else 5e-5
             assert np.abs(got - want).max() <= tol * np.abs(want).max() + 1e-7, (name, np.abs(got - want).max(), np.abs(want).max())
             cos = float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
-            assert cos > 0.9995, (name, cos)
+            assert cos > 0.99999, (name, cos)
     for name in ("encoder", "encoder_ambient"):
         gt = getattr(m, name).embeddings.grad
         rows = torch.from_numpy(gold[f"train_{tag}_gradrows::{name}"]).long().cuda()
         want = gold[f"train_{tag}_gradvals::{name}"]
         got = n(gt[rows])
-        # table rows also collect the ambient path's piecewise-constant term (enc_x feeds ambient_net): same ~2 % stability
-        assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max() + 1e-7, name
-        assert float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30)) > 0.9995, name
+        # table rows also collect the ambient path's piecewise-constant term (enc_x feeds ambient_net): the same few samples,
+        # achieved 3.5e-3 (xyz table) / 2.2e-3 (ambient table)
+        assert np.abs(got - want).max() <= 8e-3 * np.abs(want).max() + 1e-7, name
+        assert float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30)) > 0.99999, name
         s, sa, nz = gold[f"train_{tag}_gradsum::{name}"]
         assert abs(float(gt.double().abs().sum()) - sa) <= 5e-3 * sa
         assert abs(float((gt.abs().sum(1) > 0).sum()) - nz) <= 0.002 * nz + 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head", ["fused", "ops"])
+def test_hip_train_branch_gradients_on_smooth_samples(hiplib, monkeypatch, head):
+    """The config-2 call with the gradient restricted to the samples at which the network is smooth in its parameters
+    (tests/golden/reference_train_stable.npz: the mask was taken from the reference model's own ambient coordinates and
+    pre-activations by hooks -- no ambient coordinate within 2e-5 of a cell boundary, no pre-activation within 1e-4 of zero;
+    74 % of the samples).  Without the cell and ReLU flips EVERY parameter gradient -- ambient_net and the audio nets
+    included, which the unrestricted sum can only hold to 5e-3 -- equals the reference's to 1e-4 of its largest entry, and
+    every 8th sample's sigma / colour / ambient output to fp32 rounding.  Both forms of the training pass: the fused forward /
+    backward kernels and the per-operator chain."""
+    stable = np.load(os.path.join(HERE, "golden", "reference_train_stable.npz"), allow_pickle=False)
+    monkeypatch.setenv("RN_TRAIN_HEAD", head)
+    scene = _train_scene("cuda")
+    m, opt = scene.model, scene.opt
+    m.train()
+    f = _reference_inputs("cuda")
+    px = torch.from_numpy(stable["train_px"]).cuda()
+    mask = torch.from_numpy(stable["mask"]).cuda().bool()
+    fired = []
+
+    def restrict(outs):
+        fired.append([t.detach().clone() for t in outs[:3]])
+        assert outs[0].shape[0] == mask.numel()
+        for t in outs:
+            if t.requires_grad:
+                t.register_hook(lambda g, k=mask: None if g is None else g * k.to(g.dtype).reshape(-1, *([1] * (g.dim() - 1))))
+
+    from radnerf.network import _train_head
+    th = _train_head()
+    if th is not None:
+        inner = th.head_forward
+
+        def head_forward(*a, **k):
+            outs = inner(*a, **k)
+            restrict(outs)
+            return outs
+        monkeypatch.setattr(th, "head_forward", head_forward)
+    hook = m.register_forward_hook(lambda mod, args, outs: restrict(outs))
+    m.zero_grad(set_to_none=True)
+    m.mean_count, m.local_step = 49152, 0
+    m.step_counter.zero_()
+    res = m.render(f["rays_o"][:, px], f["rays_d"][:, px], f["auds"], f["bg_coords"][:, px], f["poses"], eye=f["eye"], index=[0],
+                   bg_color=f["bg_color"][:, px], staged=False, perturb=False, force_all_rays=False, dt_gamma=opt.dt_gamma,
+                   max_steps=opt.max_steps)
+    g = cases.rm_inputs(17)
+    loss = (res["image"].reshape(-1, 3) * g(4096, 3, lo=-1, hi=1).cuda()).sum() + (res["weights_sum"] * g(4096, lo=-1, hi=1).cuda()).sum() \
+        + (res["ambient"] * g(4096, lo=-1, hi=1).cuda()).sum()
+    loss.backward()
+    hook.remove()
+    assert len(fired) == 1, "the network's outputs were not seen exactly once"
+    n = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    live = int(stable["counter"][0])                              # rows past the marcher's count are padding
+    for name, t in zip(("sigma", "color", "ambient"), fired[0]):
+        want = stable[f"every8::{name}"][: (live + 7) // 8]
+        got = n(t[::8])[: want.shape[0]].reshape(want.shape)
+        d = np.abs(got - want)
+        print(f"{name}: max |d| = {d.max():.2e} (max |ref| = {np.abs(want).max():.2e})")
+        assert d.max() <= {"sigma": 2e-5, "color": 2e-6, "ambient": 2e-7}[name] * max(1.0, float(np.abs(want).max())), name
+    assert np.array_equal(n(m.step_counter[0]).astype(np.int32), stable["counter"])
+    assert abs(float(loss) - float(stable["loss"])) <= 2e-3 * abs(float(stable["loss"]))
+    params = dict(m.named_parameters())
+    worst = {}
+    for key in stable.files:
+        if key.startswith("grad::"):
+            name = key.split("::")[1]
+            got = n(params[name].grad if name != "individual_codes" else params[name].grad[:1])
+            want = stable[key]
+            worst[name] = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+    for name in ("encoder", "encoder_ambient"):
+        gt = getattr(m, name).embeddings.grad
+        rows = torch.from_numpy(stable[f"gradrows::{name}"]).long().cuda()
+        want = stable[f"gradvals::{name}"]
+        got = n(gt[rows])
+        worst[name] = float(np.abs(got - want).max() / np.abs(want).max())
+        s, sa, nz = stable[f"gradsum::{name}"]
+        assert abs(float(gt.double().abs().sum()) - sa) <= 2e-3 * sa
+        assert abs(float((gt.abs().sum(1) > 0).sum()) - nz) <= 0.002 * nz + 2
+    print("smooth-sample gradients, max |d| / max |ref|:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) <= 1e-4, worst          # achieved: 2.6e-5 (ambient table), <= 1.3e-5 everything else
