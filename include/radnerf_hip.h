@@ -109,6 +109,22 @@ int rn_march_rays_train_budget(const float *rays_o, const float *rays_d, const u
                                uint32_t M, const int32_t *M_dev, const float *nears, const float *fars,
                                float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                                const float *noises, void *workspace, rn_stream_t stream);
+/* A training step's marcher in ONE launch (no counterpart in the reference, which calls near_far_from_aabb, zeroes its
+ * counters and calls march_rays_train: raymarching/raymarching.py:19-49, 187-262, nerf/renderer.py:183, 209-213):
+ * near / far against `aabb` (written to nears / fars), count pass, ordered slices, write pass, and the counters SET to
+ * (samples of this step, N) -- not added to.  Same rays / xyzs / dirs / deltas as rn_near_far_from_aabb +
+ * rn_march_rays_train_budget on zeroed counters, except that the buffers need NOT be zero on entry: the slice of a ray
+ * the budget cuts is cleared by the launch, so rows [0, min(counter[0], M)) are all defined; rows beyond are not touched.
+ * The workgroups exchange their counts inside the launch, so all ceil(N / 256) of them must be resident together:
+ * N <= 256 * (number of CUs), else RN_ERR_INVALID_ARG.  `state`: rn_march_rays_train_step_state(N) bytes, 8-byte aligned,
+ * zeroed ONCE by the caller and then left to these launches (word 0 = launch epoch, word 1 = launches whose exchange
+ * timed out -- must stay 0; such a step reports counter[0] = 0 and marks every ray empty).  noises may be NULL (no jitter). */
+size_t rn_march_rays_train_step_state(uint32_t N);
+int rn_march_rays_train_step(const float *rays_o, const float *rays_d, const uint8_t *grid, const float *aabb,
+                             float min_near, float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C,
+                             uint32_t H, uint32_t M, const int32_t *M_dev, const float *noises, float *nears,
+                             float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                             void *state, rn_stream_t stream);
 /* raymarching.h:15  march_rays_train_backward   (raymarching.cu:535-593) */
 int rn_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays,
                                  const float *deltas, uint32_t N, uint32_t M, float *grad_rays_o,

@@ -127,6 +127,48 @@ struct Dda {
         t_io = t;
         return step;
     }
+
+    // The same walk, remembering where each sample was taken instead of writing it: rec[k * stride] = t of sample k.
+    // emit() rebuilds the sample from that t with the expressions of cell_of() / walk<true>() -- same bits -- so a caller that
+    // must know every ray's count before it can place the samples (the training marcher) walks once, not twice.
+    __device__ __forceinline__ uint32_t walk_record(float &t_io, uint32_t limit, float *rec, uint32_t stride) const {
+        float t = t_io;
+        uint32_t step = 0;
+        uint32_t guard = 0;
+        while (t < far && step < limit && guard < (1u << 20)) {
+            float x, y, z, dt, mip_bound;
+            int nx, ny, nz;
+            const uint32_t index = cell_of(t, x, y, z, dt, mip_bound, nx, ny, nz);
+            if (grid[index >> 3] & (1u << (index & 7u))) {
+                rec[step * stride] = t;
+                t += dt;
+                step++;
+            } else {
+                const float sx = copysignf(1.0f, dx), sy = copysignf(1.0f, dy), sz = copysignf(1.0f, dz);
+                const float tx = ((((float)nx + 0.5f + 0.5f * sx) * rH * 2 - 1) * mip_bound - x) * rdx;
+                const float ty = ((((float)ny + 0.5f + 0.5f * sy) * rH * 2 - 1) * mip_bound - y) * rdy;
+                const float tz = ((((float)nz + 0.5f + 0.5f * sz) * rH * 2 - 1) * mip_bound - z) * rdz;
+                const float tt = fminf(t + fmaxf(0.0f, fminf(tx, fminf(ty, tz))), far);
+                do {
+                    t += clampf(t * dt_gamma, dt_min, dt_max);
+                    guard++;
+                } while (t < tt && guard < (1u << 20));
+            }
+            guard++;
+        }
+        t_io = t;
+        return step;
+    }
+
+    __device__ __forceinline__ void emit(float t, float *xyz, float *dir, float *delta) const {
+        xyz[0] = clampf(ox + t * dx, -bound, bound);
+        xyz[1] = clampf(oy + t * dy, -bound, bound);
+        xyz[2] = clampf(oz + t * dz, -bound, bound);
+        dir[0] = dx; dir[1] = dy; dir[2] = dz;
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        delta[0] = dt;
+        delta[1] = t + dt;
+    }
 };
 
 }  // namespace rn

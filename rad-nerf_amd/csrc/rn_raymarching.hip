@@ -17,14 +17,10 @@ constexpr float kRPi = 0.3183098861837907f;
 
 // ------------------------------------------------------------------------------------------------
 // near / far  (raymarching.cu:91-145)
-__global__ void __launch_bounds__(kBlock)
-k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-           const float *__restrict__ aabb, uint32_t N, float min_near,
-           float *__restrict__ nears, float *__restrict__ fars) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+__device__ __forceinline__ void near_far_of(const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ aabb,
+                                            float min_near, float &near_out, float &far_out) {
+    const float ox = o[0], oy = o[1], oz = o[2];
+    const float dx = d[0], dy = d[1], dz = d[2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
 
     float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
@@ -45,8 +41,20 @@ k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             if (near < min_near) near = min_near;
         }
     }
-    nears[n] = miss ? FLT_MAX : near;
-    fars[n] = miss ? FLT_MAX : far;
+    near_out = miss ? FLT_MAX : near;
+    far_out = miss ? FLT_MAX : far;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+           const float *__restrict__ aabb, uint32_t N, float min_near,
+           float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    float near, far;
+    near_far_of(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, aabb, min_near, near, far);
+    nears[n] = near;
+    fars[n] = far;
 }
 
 // sph_from_ray  (raymarching.cu:162-198)
@@ -352,6 +360,130 @@ __global__ void k_march_train_counter(int32_t *counter, const uint32_t *block_su
     }
 }
 
+// The training marcher of ONE step in ONE launch (rn_march_rays_train_step): near / far (raymarching.cu:91-145), the count
+// pass, the ordered slice reservation, the write pass and the step's counters (raymarching.cu:352-518) -- what
+// rn_near_far_from_aabb + a memset of the counters + rn_march_rays_train_budget's three kernels do in five launches; at 4 096
+// rays these are 16 workgroups whose time is the length of one ray's walk, so the launches cost more than the work.
+// The counts cross workgroups inside the launch: workgroup b stores (launch tag, its sample count) as one 64-bit word with an
+// agent-scope release store, and every workgroup waits until all n_blocks words carry this launch's tag (they are its barrier
+// and its scan at once: the sum of the words before b is b's offset, the sum of all is the step's sample count).  The tag is a
+// launch epoch kept in `state` (zero-initialised once by the caller, then owned by these launches): read by every workgroup
+// before it stores its word, bumped by workgroup 0 after it has seen all words -- so nobody can read the new value early.
+// All workgroups must be resident together (the host refuses more than one per CU); the wait is bounded all the same: a
+// workgroup that gives up counts in state[1], and the step then reports zero samples (counter[0] = 0) instead of rows built on
+// stale offsets.
+// The counters are SET (counter[0] = samples, counter[1] = N), not added to: a training step starts them from zero
+// (renderer.py:209-211), which is the memset this launch replaces.
+// RECORD (max_steps <= kRecSteps): the count pass remembers the t of every sample in LDS and the write pass rebuilds the samples
+// from them (Dda::emit: the same expressions) instead of walking the grid a second time -- the walk is the launch's whole time.
+constexpr uint32_t kStepPolls = 1u << 20;
+constexpr uint32_t kRecSteps = 32;
+
+template <bool RECORD>
+__global__ void __launch_bounds__(kBlock)
+k_march_train_step(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid,
+                   const float *__restrict__ aabb, float min_near, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                   uint32_t C, uint32_t H, uint32_t M, const int32_t *__restrict__ M_dev, const float *__restrict__ noises,
+                   float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                   float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *__restrict__ counter, uint32_t *state,
+                   unsigned long long *words) {
+    __shared__ uint32_t lds[kBlock / kWave];
+    __shared__ uint32_t wave_tot[kBlock / kWave];
+    __shared__ uint32_t stalled;
+    __shared__ float t_rec[RECORD ? kRecSteps * kBlock : 1];      // [sample][lane]: conflict-free
+    const uint32_t n_blocks = gridDim.x;
+    const uint32_t tag = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (threadIdx.x == 0) stalled = 0u;
+    uint32_t budget = M;                                       // M: rows the buffers hold; *M_dev: this step's sample budget
+    if (M_dev) { const uint32_t b = (uint32_t)*M_dev; budget = b < M ? b : M; }
+
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t num_steps = 0;
+    float near = FLT_MAX, far = FLT_MAX, t0 = 0.0f;
+    if (n < N) {
+        near_far_of(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, aabb, min_near, near, far);
+        nears[n] = near;
+        fars[n] = far;
+        Dda s;
+        s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid, far);
+        t0 = near;
+        t0 += clampf(t0 * dt_gamma, s.dt_min, s.dt_max) * (noises ? noises[n] : 0.0f);  // :392
+        float t = t0;
+        if constexpr (RECORD) num_steps = s.walk_record(t, max_steps, t_rec + threadIdx.x, kBlock);
+        else num_steps = s.walk<false>(t, max_steps, nullptr, nullptr, nullptr);
+    }
+    const uint32_t sum = block_reduce_sum(num_steps, lds);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&words[blockIdx.x], ((unsigned long long)tag << 32) | sum, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+
+    // barrier + scan: every workgroup's word of THIS launch
+    uint32_t part = 0, all = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock) {
+        unsigned long long w = __hip_atomic_load(&words[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t polls = 0;
+        while ((uint32_t)(w >> 32) != tag) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > kStepPolls) { stalled = 1u; break; }
+            w = __hip_atomic_load(&words[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t cnt = (uint32_t)(w & 0xffffffffull);
+        all += cnt;
+        part += b < blockIdx.x ? cnt : 0u;
+    }
+    const uint32_t block_off = block_reduce_sum(part, lds);
+    const uint32_t total = block_reduce_sum(all, lds);         // (the reductions' barriers also publish `stalled`)
+    const bool bad = stalled != 0u;
+
+    // exclusive scan of num_steps inside the workgroup (as k_march_train_write)
+    uint32_t incl = num_steps;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; w++) before += wave_tot[w];
+    const uint32_t point_index = block_off + before + (incl - num_steps);
+
+    if (n < N) {
+        rays[n * 3] = (int32_t)n;
+        rays[n * 3 + 1] = (int32_t)point_index;
+        const bool fits = !bad && point_index + num_steps <= budget;
+        rays[n * 3 + 2] = fits ? (int32_t)num_steps : 0;   // a ray beyond the budget is marked empty (see k_march_train_write)
+        if (num_steps != 0 && fits) {
+            Dda s;
+            s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid, far);
+            if constexpr (RECORD) {
+                for (uint32_t k = 0; k < num_steps; k++) {
+                    const size_t r = (size_t)point_index + k;
+                    s.emit(t_rec[k * kBlock + threadIdx.x], xyzs + r * 3, dirs + r * 3, deltas + r * 2);
+                }
+            } else {
+                float t = t0;
+                s.walk<true>(t, num_steps, xyzs + (size_t)point_index * 3, dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
+            }
+        } else if (num_steps != 0 && !bad) {
+            // The slice of a ray that does not fit is cleared (up to the buffers' capacity): the network pass visits rows
+            // [0, min(counter[0], capacity)), whose rows then all hold either a sample or zeros -- the caller need not memset
+            // the buffers (rn_march_rays_train_budget relies on one).
+            for (uint32_t k = 0; k < num_steps && point_index + k < M; k++) {
+                const size_t r = (size_t)point_index + k;
+                xyzs[r * 3] = 0.0f; xyzs[r * 3 + 1] = 0.0f; xyzs[r * 3 + 2] = 0.0f;
+                dirs[r * 3] = 0.0f; dirs[r * 3 + 1] = 0.0f; dirs[r * 3 + 2] = 0.0f;
+                deltas[r * 2] = 0.0f; deltas[r * 2 + 1] = 0.0f;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counter[0] = bad ? 0 : (int32_t)total;
+        counter[1] = (int32_t)N;
+        if (bad) atomicAdd(&state[1], 1u);
+        __hip_atomic_store(&state[0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every workgroup has read the old epoch
+    }
+}
+
 // raymarching.cu:535-583
 __global__ void __launch_bounds__(kBlock)
 k_march_train_backward(const float *__restrict__ grad_xyzs, const float *__restrict__ grad_dirs,
@@ -531,6 +663,42 @@ int rn_march_rays_train_budget(const float *rays_o, const float *rays_d, const u
     hipLaunchKernelGGL(k_march_train_counter, dim3(1), dim3(kBlock), 0, as_stream(stream), counter, block_sums,
                        blocks, N);
     return check_launch("march_rays_train");
+}
+
+size_t rn_march_rays_train_step_state(uint32_t N) { return (size_t)(2 + 2 * div_up(N, kBlock)) * sizeof(uint32_t); }
+
+static int step_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+int rn_march_rays_train_step(const float *rays_o, const float *rays_d, const uint8_t *grid, const float *aabb, float min_near,
+                             float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                             const int32_t *M_dev, const float *noises, float *nears, float *fars, float *xyzs, float *dirs,
+                             float *deltas, int32_t *rays, int32_t *counter, void *state, rn_stream_t stream) {
+    if (N == 0) return RN_OK;
+    RN_REQUIRE(rays_o && rays_d && grid && aabb && nears && fars && xyzs && dirs && deltas && rays && counter && state,
+               "march_rays_train_step: null pointer");
+    RN_REQUIRE(((uintptr_t)state & 7u) == 0, "march_rays_train_step: state must be 8-byte aligned");
+    RN_REQUIRE(C >= 1 && C <= 16 && H >= 1 && max_steps >= 1, "march_rays_train_step: bad C/H/max_steps");
+    const uint32_t blocks = div_up(N, kBlock);
+    RN_REQUIRE(blocks <= (uint32_t)step_cus(), "march_rays_train_step: %u rays need %u workgroups resident together, the device has %d CUs "
+               "(use rn_march_rays_train_budget)", N, blocks, step_cus());
+    uint32_t *st = static_cast<uint32_t *>(state);
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(st + 2);
+    if (max_steps <= kRecSteps)
+        hipLaunchKernelGGL(k_march_train_step<true>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, grid, aabb, min_near,
+                           bound, dt_gamma, max_steps, N, C, H, M, M_dev, noises, nears, fars, xyzs, dirs, deltas, rays, counter, st, words);
+    else
+        hipLaunchKernelGGL(k_march_train_step<false>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, grid, aabb, min_near,
+                           bound, dt_gamma, max_steps, N, C, H, M, M_dev, noises, nears, fars, xyzs, dirs, deltas, rays, counter, st, words);
+    return check_launch("march_rays_train_step");
 }
 
 int rn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,

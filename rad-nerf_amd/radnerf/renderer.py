@@ -173,14 +173,37 @@ class NeRFRenderer(nn.Module):
             self.last_stats["live_samples"] = int(live.item())
         return acc
 
-    def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps, wait_for=None):
+    def _step_marcher_ok(self, rays_o, force_all_rays):
+        """The one-launch marcher of a budgeted training step: a device-side budget is set, the rays fit one workgroup per CU."""
+        import os
+        if getattr(self, "_sample_budget", None) is None or force_all_rays or self.mean_count <= 0 or not rays_o.is_cuda:
+            return False
+        if os.environ.get("RN_TRAIN_MARCH", "step") != "step" or not torch.is_grad_enabled() or torch.is_autocast_enabled():
+            return False
+        from raymarching.ops import step_marcher_supported
+        return step_marcher_supported(rays_o.shape[0], rays_o.device)
+
+    def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps, wait_for=None,
+                       box=None):
         """Train branch (renderer.py:206-223): every sample of every ray, packed; one sample counter per step (ring of 16)."""
         counter = getattr(self, "_static_counter", None)           # a captured training step counts into a fixed pair
         if counter is None:
             counter = self.step_counter[self.local_step % 16]
+        budget = getattr(self, "_sample_budget", None)             # (device int32 budget, row capacity): see radnerf/train.py
+        from .network import _train_glue, _train_head
+        th = _train_head()
+        if nears is None:
+            # one launch: near / far, count, slices, samples, counters (set, not added to).  The fused network pass stops at the
+            # counter, below which the launch has written every row -- no memset of the sample buffers for it.
+            from raymarching.ops import march_rays_train_step
+            self.local_step += 1
+            fused_head = th is not None and th.usable(self, rays_o, enc_a)
+            nears, fars, xyzs, dirs, deltas, rays = march_rays_train_step(rays_o, rays_d, box, self.min_near, self.bound, self.density_bitfield,
+                                                                          self.cascade, self.grid_size, counter, budget[0], budget[1], perturb,
+                                                                          dt_gamma, max_steps, not fused_head)
+            return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for)
         counter.zero_()
         self.local_step += 1
-        budget = getattr(self, "_sample_budget", None)             # (device int32 budget, row capacity): see radnerf/train.py
         if budget is not None and not force_all_rays and self.mean_count > 0:
             from raymarching.ops import march_rays_train_budget
             xyzs, dirs, deltas, rays = march_rays_train_budget(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
@@ -190,6 +213,10 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
+        return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for)
+
+    def _head_network(self, xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for):
+        """The network over a step's samples + the training compositor (renderer.py:213-223)."""
         if wait_for is not None:                 # the audio code was computed on a side stream (run_cuda)
             main = torch.cuda.current_stream(xyzs.device)
             main.wait_stream(wait_for)
@@ -210,7 +237,7 @@ class NeRFRenderer(nn.Module):
         if self.density_scale != 1:
             sigmas = self.density_scale * sigmas
         weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient_abs, deltas, rays)
-        return dict(weights_sum=weights_sum, ambient=ambient_sum, depth=depth, image=image)
+        return dict(weights_sum=weights_sum, ambient=ambient_sum, depth=depth, image=image, nears=nears, fars=fars)
 
     # ---------------------------------------------------------------------------------------------- torso layer
     def _torso_layer(self, bg_coords, poses, enc_a, index, background, results):
@@ -281,14 +308,19 @@ class NeRFRenderer(nn.Module):
             th = _train_head()
             if th is not None and th.overlap_enabled():
                 audio_side = th.side_stream(rays_o.device, 1)
+        # a step with a device-side sample budget (radnerf/train.py) marches in ONE launch that also intersects the rays with the
+        # box and sets the step's counters (raymarching.ops.march_rays_train_step): no near/far launch here then
+        one_launch = self.training and self._step_marcher_ok(rays_o, force_all_rays)
         if audio_side is not None:
             main = torch.cuda.current_stream(rays_o.device)
             audio_side.wait_stream(main)
             with torch.cuda.stream(audio_side):
                 enc_a = self._audio_code(auds)
-            nears, fars = (t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
+            nears, fars = (None, None) if one_launch else (
+                t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
         else:
-            nears, fars = (t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
+            nears, fars = (None, None) if one_launch else (
+                t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
             enc_a = self._audio_code(auds)
         ind_code = None
         if self.individual_dim > 0:
@@ -312,7 +344,8 @@ class NeRFRenderer(nn.Module):
         results = {}
         if self.training:
             head = self._head_training(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps,
-                                       wait_for=audio_side)
+                                       wait_for=audio_side, box=box)
+            nears, fars = head["nears"], head["fars"]
             results["weights_sum"], results["ambient"] = head["weights_sum"], head["ambient"]
         else:
             head = self._head_inference_ops(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, dt_gamma, max_steps, T_thresh)

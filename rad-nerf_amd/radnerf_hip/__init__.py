@@ -35,6 +35,8 @@ _SIGNATURES = {
                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_march_rays_train_budget": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_march_rays_train_step": [_ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                 _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_march_rays_train_backward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_composite_rays_train_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr,
                                         _ptr],
@@ -72,6 +74,8 @@ _lib.rn_version.restype = C.c_int
 _lib.rn_device_count.restype = C.c_int
 _lib.rn_march_rays_train_workspace.restype = _sz
 _lib.rn_march_rays_train_workspace.argtypes = [_u32]
+_lib.rn_march_rays_train_step_state.restype = _sz
+_lib.rn_march_rays_train_step_state.argtypes = [_u32]
 _lib.rn_compact_rays_workspace.restype = _sz
 _lib.rn_compact_rays_workspace.argtypes = [_u32]
 _lib.rn_grid_encode_forward_workspace.restype = _sz
@@ -93,7 +97,8 @@ _lib.rn_prof_durations.restype = C.c_int
 def exported_symbols():
     """Every symbol include/radnerf_hip.h declares (used by the CPU-side load test)."""
     return sorted(list(_SIGNATURES) + ["rn_last_error", "rn_version", "rn_device_count", "rn_prof_enable", "rn_prof_pause",
-                                       "rn_prof_collect", "rn_prof_durations", "rn_march_rays_train_workspace", "rn_compact_rays_workspace",
+                                       "rn_prof_collect", "rn_prof_durations", "rn_march_rays_train_workspace", "rn_march_rays_train_step_state",
+                                       "rn_compact_rays_workspace",
                                        "rn_grid_encode_forward_workspace"])
 
 

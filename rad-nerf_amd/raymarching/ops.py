@@ -215,6 +215,70 @@ class _march_rays_train_budget(Function):
         return _march_rays_train.backward(ctx, grad_xyzs, grad_dirs, grad_deltas, grad_rays)[:14]
 
 
+_STEP_STATE = {}
+
+
+def _step_state(N, device):
+    """Persistent exchange words of rn_march_rays_train_step for launches of N rays on `device` (zeroed once, then owned by the
+    launches: see include/radnerf_hip.h)."""
+    key = (device.index, int(N))
+    st = _STEP_STATE.get(key)
+    if st is None:
+        st = _STEP_STATE[key] = torch.zeros(int(hip._lib.rn_march_rays_train_step_state(int(N))) // 4, dtype=torch.int32, device=device)
+    return st
+
+
+def step_marcher_supported(N, device):
+    """One workgroup of 256 rays per CU at most (the workgroups exchange their counts inside the launch)."""
+    return device.type == "cuda" and (N + 255) // 256 <= torch.cuda.get_device_properties(device).multi_processor_count
+
+
+class _march_rays_train_step(Function):
+    """A training step's marcher as ONE launch (rn_march_rays_train_step; not in the reference's surface): near / far against
+    `aabb`, count pass, ordered slices, write pass, counters -- what near_far_from_aabb + `step_counter.zero_()` +
+    march_rays_train_budget do in five.  `step_counter` is SET to (samples, N).  `zeroed`: hand out zero-filled sample buffers
+    (a network pass that visits every row of the capacity needs them; the fused training pass stops at step_counter[0], and
+    every row below it is written by the launch).  Returns nears, fars, xyzs, dirs, deltas, rays."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=_f32)
+    def forward(ctx, rays_o, rays_d, aabb, min_near, bound, density_bitfield, C, H, step_counter, budget, capacity, perturb=False,
+                dt_gamma=0, max_steps=1024, zeroed=True):
+        rays_o, rays_d = _rays(rays_o, rays_d)
+        density_bitfield = hip.dev(density_bitfield).contiguous()
+        aabb = hip.dev(aabb).contiguous()
+        device = rays_o.device
+        N, M = rays_o.shape[0], int(capacity)
+        if zeroed:
+            xyzs, dirs, deltas = _sample_buffers(M, device)
+        else:
+            buf = torch.empty(M * 8, dtype=_f32, device=device)
+            xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=device)
+        nf = torch.empty(2, N, dtype=_f32, device=device)
+        noises = torch.rand(N, dtype=_f32, device=device) if perturb else None
+        state = _step_state(N, device)
+        hip.call("rn_march_rays_train_step", hip.ptr(rays_o, _f32), hip.ptr(rays_d, _f32), hip.ptr(density_bitfield, torch.uint8),
+                 hip.ptr(aabb, _f32), float(min_near), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), M,
+                 hip.ptr(budget, torch.int32), hip.ptr(noises), hip.ptr(nf[0]), hip.ptr(nf[1]), hip.ptr(xyzs), hip.ptr(dirs), hip.ptr(deltas),
+                 hip.ptr(rays), hip.ptr(step_counter, torch.int32), hip.ptr(state), hip.stream())
+        ctx.save_for_backward(rays, deltas)
+        ctx.mark_non_differentiable(nf, rays)
+        return nf[0], nf[1], xyzs, dirs, deltas, rays
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_nears, g_fars, grad_xyzs, grad_dirs, grad_deltas, grad_rays):
+        g = _march_rays_train.backward(ctx, grad_xyzs, grad_dirs, grad_deltas, grad_rays)
+        return (g[0], g[1]) + (None,) * 13
+
+
+def march_rays_train_step(rays_o, rays_d, aabb, min_near, bound, density_bitfield, C, H, step_counter, budget, capacity, perturb=False,
+                          dt_gamma=0, max_steps=1024, zeroed=True):
+    return _march_rays_train_step.apply(rays_o, rays_d, aabb, min_near, bound, density_bitfield, C, H, step_counter, budget, capacity,
+                                        perturb, dt_gamma, max_steps, zeroed)
+
+
 def march_rays_train_budget(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, budget, capacity, perturb=False,
                             dt_gamma=0, max_steps=1024):
     return _march_rays_train_budget.apply(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, budget, capacity,

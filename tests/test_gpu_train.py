@@ -261,6 +261,72 @@ def test_device_budget_marcher_equals_the_host_budget_marcher(hiplib, budget_fra
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("budget_frac", [1.3, 0.6])
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("max_steps", [16, 48])
+def test_one_launch_step_marcher_equals_the_five_launch_chain(hiplib, budget_frac, perturb, max_steps):
+    """rn_march_rays_train_step (near / far + count + ordered slices + samples + counters in ONE launch, counts exchanged between
+    workgroups inside it) against near_far_from_aabb + zeroed counters + rn_march_rays_train_budget: identical nears / fars, rays,
+    counters and sample rows; on buffers that were NOT zeroed (NaN-filled here) every row below min(counter[0], capacity) is
+    defined -- samples, or zeros where the budget cut a ray -- and nothing beyond is touched.  Run several times over: the launch
+    epoch in the persistent state words must carry from one launch to the next, and no launch may time out.  max_steps 16: the
+    launch records its samples' t in LDS and rebuilds them; 48: it walks twice."""
+    import raymarching
+    from raymarching import ops
+    scene = _scene(64)
+    m, f = scene.model, scene.frame(0)
+    o, d = f["rays_o"].reshape(-1, 3).contiguous(), f["rays_d"].reshape(-1, 3).contiguous()
+    N = o.shape[0]
+    assert ops.step_marcher_supported(N, o.device) and (N + 255) // 256 > 4      # several workgroups exchange counts
+    nears, fars = raymarching.near_far_from_aabb(o, d, m.aabb_train, m.min_near)
+    c0 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    raymarching.march_rays_train(o, d, m.bound, m.density_bitfield, m.cascade, m.grid_size, nears, fars, c0, -1, False, 128, True,
+                                 scene.opt.dt_gamma, max_steps)
+    total = int(c0[0].item())
+    budget = int(total * budget_frac)
+    budget += 128 - budget % 128
+    cap = budget + 3000
+    bt = torch.tensor([budget], dtype=torch.int32, device="cuda")
+    state = ops._step_state(N, o.device)
+    for rep in range(3):
+        seed = 11 + rep
+        torch.manual_seed(seed)
+        c1 = torch.zeros(2, dtype=torch.int32, device="cuda")
+        x1, d1, dl1, r1 = ops.march_rays_train_budget(o, d, m.bound, m.density_bitfield, m.cascade, m.grid_size, nears, fars, c1, bt, cap,
+                                                      perturb, scene.opt.dt_gamma, max_steps)
+        torch.manual_seed(seed)                                   # the same jitter draw
+        c2 = torch.full((2,), 12345, dtype=torch.int32, device="cuda")     # SET by the launch, whatever it held
+        epoch = int(state[0].item())
+        n2, f2, x2, d2, dl2, r2 = ops.march_rays_train_step(o, d, m.aabb_train, m.min_near, m.bound, m.density_bitfield, m.cascade,
+                                                            m.grid_size, c2, bt, cap, perturb, scene.opt.dt_gamma, max_steps, True)
+        assert int(state[0].item()) == epoch + 1 and int(state[1].item()) == 0
+        assert torch.equal(n2, nears) and torch.equal(f2, fars)
+        assert torch.equal(c1, c2) and torch.equal(r1, r2)
+        assert torch.equal(x1, x2) and torch.equal(d1, d2) and torch.equal(dl1, dl2)
+    # buffers the caller did not zero
+    real_empty = torch.empty
+
+    def nan_empty(*a, **k):
+        t = real_empty(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+    torch.manual_seed(11)
+    c3 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    try:
+        torch.empty = nan_empty
+        n3, f3, x3, d3, dl3, r3 = ops.march_rays_train_step(o, d, m.aabb_train, m.min_near, m.bound, m.density_bitfield, m.cascade,
+                                                            m.grid_size, c3, bt, cap, perturb, scene.opt.dt_gamma, max_steps, False)
+    finally:
+        torch.empty = real_empty
+    torch.manual_seed(11)
+    c1 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    x1, d1, dl1, r1 = ops.march_rays_train_budget(o, d, m.bound, m.density_bitfield, m.cascade, m.grid_size, nears, fars, c1, bt, cap, perturb,
+                                                  scene.opt.dt_gamma, max_steps)
+    live = min(int(c3[0].item()), cap)
+    assert torch.equal(c3, c1) and torch.equal(r3, r1)
+    assert torch.equal(x3[:live], x1[:live]) and torch.equal(d3[:live], d1[:live]) and torch.equal(dl3[:live], dl1[:live])
+    assert bool(torch.isnan(x3[live:]).all()) and bool(torch.isnan(dl3[live:]).all())
+
+
 def test_graphed_trainer_keeps_its_graph_when_the_budget_moves(hiplib):
     """The sample budget is a device scalar of the captured step: mean_count moving inside the capacity window costs no capture,
     leaving it costs one."""
