@@ -47,6 +47,10 @@ size_t rn_train_head_wgrad_workspace(void);
  * biases: W_amb0[:, 32:] enc_a | W_sig0[:, 64] eye | W_col0[:, 80:] ind_code (nerf/network.py:236, 262, 274). */
 int rn_train_head_pack(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code, float *image,
                        rn_stream_t stream);
+/* The same with the individual code picked on the device: ind_table = individual_codes [rows, ind_dim], *ind_index (int64 device
+ * scalar) the row -- nerf/renderer.py:199's `self.individual_codes[index]` without an index_select launch. */
+int rn_train_head_pack_row(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_table,
+                           const int64_t *ind_index, float *image, rn_stream_t stream);
 
 /* Forward for M sample rows (m_dev: device int32 live count, clipped to M; NULL = M).  xyzs in [-bound, bound], dirs unit
  * vectors.  Outputs: sigmas [M], rgbs [M,3], ambient [M,2] (after tanh), ambient_abs [M] (|a0| + |a1|, nerf/renderer.py:216;
@@ -75,6 +79,12 @@ typedef struct {
 int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
                                uint32_t M, const int32_t *m_dev, const float *workspace, const rn_train_head_grads_t *grads,
                                void *wgrad_workspace, rn_stream_t stream);
+/* Row form (see rn_train_head_pack_row): ind_table / g->ind_code are [ind_rows, ind_dim]; the launch that writes the constants'
+ * gradients writes the picked row of g->ind_code and zeros everywhere else -- the whole gradient of individual_codes, which
+ * index_select's backward builds with a memset and an index_add. */
+int rn_train_head_weight_grads_row(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_table,
+                                   const int64_t *ind_index, uint32_t ind_rows, uint32_t M, const int32_t *m_dev, const float *workspace,
+                                   const rn_train_head_grads_t *g, void *wgrad_workspace, rn_stream_t stream);
 
 /* Table gradient of one grid from level-major feature gradients: grad_table[row(l, corner)] += w_corner * grad[l, b, :]
  * (kernel_grid_backward, gridencoder.cu:247-339) for b < live count; inputs [M, D] normalised coordinates (rows outside

@@ -67,9 +67,11 @@ __host__ __device__ constexpr int gather_feature(int j) {
 }
 
 __global__ void __launch_bounds__(256) k_train_pack(RawW w, const float *__restrict__ enc_a, const float *__restrict__ eye,
-                                                    const float *__restrict__ ind_code, float *__restrict__ image) {
+                                                    const float *__restrict__ ind_code, const int64_t *__restrict__ ind_index,
+                                                    float *__restrict__ image) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= kImage) return;
+    if (ind_index) ind_code += (size_t)ind_index[0] * w.ind_dim;   // ind_code = the table individual_codes, row picked on the device
     const int ldA0 = 32 + (int)w.audio_dim, ldS0 = 64 + (int)w.has_eye, ldC0 = 80 + (int)w.ind_dim;
     float v;
     auto mfma_elem = [&](int q, const float *src, int ld, int kind) -> float {
@@ -792,15 +794,26 @@ struct CArgs {
     const float *enc_a, *eye, *ind_code;
     const float *gb;    // [3][64]
     float *g_a0, *g_s0, *g_c0, *g_enc_a, *g_eye, *g_ind;
+    const int64_t *ind_index;   // non-NULL: ind_code / g_ind are the tables [ind_rows, ind_dim]; the row is picked here and the
+    uint32_t ind_rows;          // rest of the gradient table is written as zeros (what index_select's backward builds in two launches)
 };
 __global__ void __launch_bounds__(256) k_train_const(CArgs p) {
     const int which = blockIdx.x;
     const float *W, *c, *gb = p.gb + 64 * which;
     float *gW, *gc;
     uint32_t n, ld, c0;
+    if (which >= 3) {           // extra workgroups (row form only): zeros for the other rows of the code gradient table
+        const size_t row = (size_t)p.ind_index[0], nd = p.w.ind_dim, total = (size_t)p.ind_rows * nd;
+        for (size_t e = (size_t)(which - 3) * 256 + threadIdx.x; e < total; e += (size_t)(gridDim.x - 3) * 256)
+            if (e / nd != row) p.g_ind[e] = 0.0f;
+        return;
+    }
     if (which == 0) { W = p.w.amb_w0; c = p.enc_a; gW = p.g_a0; gc = p.g_enc_a; n = p.w.audio_dim; c0 = 32; }
     else if (which == 1) { W = p.w.sig_w0; c = p.eye; gW = p.g_s0; gc = p.g_eye; n = p.w.has_eye; c0 = 64; }
-    else { W = p.w.col_w0; c = p.ind_code; gW = p.g_c0; gc = p.g_ind; n = p.w.ind_dim; c0 = 80; }
+    else {
+        W = p.w.col_w0; c = p.ind_code; gW = p.g_c0; gc = p.g_ind; n = p.w.ind_dim; c0 = 80;
+        if (p.ind_index) { c += (size_t)p.ind_index[0] * n; if (gc) gc += (size_t)p.ind_index[0] * n; }
+    }
     ld = c0 + n;
     for (uint32_t e = threadIdx.x; e < 64 * n; e += 256) {
         const uint32_t u = e / n, a = e - u * n;
@@ -1284,8 +1297,19 @@ int rn_train_head_pack(const rn_nerf_weights_t *w, const float *enc_a, const flo
     if (int rc = check_w(w)) return rc;
     RN_REQUIRE(image && ((uintptr_t)image & 15u) == 0, "train_head_pack: image must be 16-byte aligned");
     RN_REQUIRE((enc_a || w->audio_dim == 0) && (eye || !w->has_eye) && (ind_code || w->ind_dim == 0), "train_head_pack: null constant");
-    hipLaunchKernelGGL(k_train_pack, dim3(div_up(kImage, 256)), dim3(256), 0, as_stream(stream), raw_w(w), enc_a, eye, ind_code, image);
+    hipLaunchKernelGGL(k_train_pack, dim3(div_up(kImage, 256)), dim3(256), 0, as_stream(stream), raw_w(w), enc_a, eye, ind_code,
+                       static_cast<const int64_t *>(nullptr), image);
     return check_launch("train_head_pack");
+}
+
+int rn_train_head_pack_row(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_table,
+                           const int64_t *ind_index, float *image, rn_stream_t stream) {
+    if (int rc = check_w(w)) return rc;
+    RN_REQUIRE(image && ((uintptr_t)image & 15u) == 0, "train_head_pack_row: image must be 16-byte aligned");
+    RN_REQUIRE((enc_a || w->audio_dim == 0) && (eye || !w->has_eye) && ind_table && ind_index && w->ind_dim, "train_head_pack_row: null constant");
+    hipLaunchKernelGGL(k_train_pack, dim3(div_up(kImage, 256)), dim3(256), 0, as_stream(stream), raw_w(w), enc_a, eye, ind_table, ind_index,
+                       image);
+    return check_launch("train_head_pack_row");
 }
 
 int rn_train_head_forward(const float *xyzs, const float *dirs, uint32_t M, const int32_t *m_dev, const rn_grid_t *grid_xyz,
@@ -1326,9 +1350,9 @@ int rn_train_head_backward(const float *grad_sigmas, const float *grad_rgbs, con
     return check_launch("train_head_backward");
 }
 
-int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
-                               uint32_t M, const int32_t *m_dev, const float *workspace, const rn_train_head_grads_t *g,
-                               void *wgrad_workspace, rn_stream_t stream) {
+static int weight_grads(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code, const int64_t *ind_index,
+                        uint32_t ind_rows, uint32_t M, const int32_t *m_dev, const float *workspace, const rn_train_head_grads_t *g,
+                        void *wgrad_workspace, rn_stream_t stream) {
     if (int rc = check_w(w)) return rc;
     RN_REQUIRE(M > 0 && workspace && g && wgrad_workspace, "train_head_weight_grads: null pointer / M == 0");
     RN_REQUIRE(g->amb_w0 && g->amb_w1 && g->amb_w2 && g->sig_w0 && g->sig_w1 && g->sig_w2 && g->col_w0 && g->col_w1,
@@ -1352,9 +1376,24 @@ int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, c
     r.job[J_C0] = RJob{g->col_w0, 64, 80, ldC0, 80, gb + 128};
     r.job[J_C1] = RJob{g->col_w1, 3, 64, 64, -1, nullptr};
     hipLaunchKernelGGL(k_train_wreduce, dim3(div_up(96 * 96, 256), kJobs), dim3(256), 0, s, r);
-    CArgs c{raw_w(w), enc_a, eye, ind_code, gb, g->amb_w0, g->sig_w0, g->col_w0, g->enc_a, g->eye, g->ind_code};
-    hipLaunchKernelGGL(k_train_const, dim3(3), dim3(256), 0, s, c);
+    CArgs c{raw_w(w), enc_a, eye, ind_code, gb, g->amb_w0, g->sig_w0, g->col_w0, g->enc_a, g->eye, g->ind_code, ind_index, ind_rows};
+    const uint32_t zero_blocks = ind_index ? (div_up(ind_rows * w->ind_dim, 1024) < 64u ? div_up(ind_rows * w->ind_dim, 1024) : 64u) : 0u;
+    hipLaunchKernelGGL(k_train_const, dim3(3 + zero_blocks), dim3(256), 0, s, c);
     return check_launch("train_head_weight_grads");
+}
+
+int rn_train_head_weight_grads(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_code,
+                               uint32_t M, const int32_t *m_dev, const float *workspace, const rn_train_head_grads_t *g,
+                               void *wgrad_workspace, rn_stream_t stream) {
+    return weight_grads(w, enc_a, eye, ind_code, nullptr, 0, M, m_dev, workspace, g, wgrad_workspace, stream);
+}
+
+int rn_train_head_weight_grads_row(const rn_nerf_weights_t *w, const float *enc_a, const float *eye, const float *ind_table,
+                                   const int64_t *ind_index, uint32_t ind_rows, uint32_t M, const int32_t *m_dev, const float *workspace,
+                                   const rn_train_head_grads_t *g, void *wgrad_workspace, rn_stream_t stream) {
+    RN_REQUIRE(ind_table && ind_index && ind_rows && g && g->ind_code && w && w->ind_dim,
+               "train_head_weight_grads_row: the code table, its row index and the gradient table are required");
+    return weight_grads(w, enc_a, eye, ind_table, ind_index, ind_rows, M, m_dev, workspace, g, wgrad_workspace, stream);
 }
 
 }  // extern "C"

@@ -183,8 +183,15 @@ class NeRFRenderer(nn.Module):
         from raymarching.ops import step_marcher_supported
         return step_marcher_supported(rays_o.shape[0], rays_o.device)
 
+    def _fused_head_expected(self, rays_o, auds):
+        """Will _head_network take the fused training kernels for this call?  (What train_head.usable() will say once the samples
+        exist: they inherit device and dtype from the rays.)"""
+        from .network import _train_head
+        th = _train_head()
+        return th is not None and auds is not None and th.usable(self, rays_o, auds)
+
     def _head_training(self, rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps, wait_for=None,
-                       box=None):
+                       box=None, ind_index=None):
         """Train branch (renderer.py:206-223): every sample of every ray, packed; one sample counter per step (ring of 16)."""
         counter = getattr(self, "_static_counter", None)           # a captured training step counts into a fixed pair
         if counter is None:
@@ -201,7 +208,7 @@ class NeRFRenderer(nn.Module):
             nears, fars, xyzs, dirs, deltas, rays = march_rays_train_step(rays_o, rays_d, box, self.min_near, self.bound, self.density_bitfield,
                                                                           self.cascade, self.grid_size, counter, budget[0], budget[1], perturb,
                                                                           dt_gamma, max_steps, not fused_head)
-            return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for)
+            return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for, ind_index)
         counter.zero_()
         self.local_step += 1
         if budget is not None and not force_all_rays and self.mean_count > 0:
@@ -213,9 +220,9 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
-        return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for)
+        return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for, ind_index)
 
-    def _head_network(self, xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for):
+    def _head_network(self, xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for, ind_index=None):
         """The network over a step's samples + the training compositor (renderer.py:213-223)."""
         if wait_for is not None:                 # the audio code was computed on a side stream (run_cuda)
             main = torch.cuda.current_stream(xyzs.device)
@@ -226,8 +233,10 @@ class NeRFRenderer(nn.Module):
         th = _train_head()
         if th is not None and th.usable(self, xyzs, enc_a):
             # one forward kernel for the network (+ |ambient| sum); the marcher's counter bounds the rows it visits
-            sigmas, rgbs, ambient, ambient_abs = th.head_forward(self, xyzs, dirs, enc_a, ind_code, eye, m_dev=counter)
+            sigmas, rgbs, ambient, ambient_abs = th.head_forward(self, xyzs, dirs, enc_a, ind_code, eye, m_dev=counter, ind_index=ind_index)
         else:
+            if ind_index is not None:       # expected the fused kernels, got the operator chain after all: pick the row here
+                ind_code = torch.index_select(self.individual_codes, 0, ind_index)
             sigmas, rgbs, ambient = self(xyzs, dirs, enc_a, ind_code, eye)
             glue = _train_glue()
             if glue is not None and ambient.dim() == 2 and ambient.shape[1] == 2 and glue.enabled(ambient):
@@ -322,7 +331,7 @@ class NeRFRenderer(nn.Module):
             nears, fars = (None, None) if one_launch else (
                 t.detach() for t in raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near))
             enc_a = self._audio_code(auds)
-        ind_code = None
+        ind_code = ind_index = None
         if self.individual_dim > 0:
             if self.training and not isinstance(index, int):
                 # index_select = the same rows as individual_codes[index] (nerf/renderer.py:199); its backward is one index_add
@@ -337,14 +346,18 @@ class NeRFRenderer(nn.Module):
                         if len(cache) > 4096:
                             cache.clear()
                         idx = cache[key] = torch.as_tensor(key, dtype=torch.long, device=self.individual_codes.device)
-                ind_code = torch.index_select(self.individual_codes, 0, idx.reshape(-1).long())
+                idx = idx.reshape(-1)
+                if idx.numel() == 1 and idx.dtype == torch.int64 and idx.is_cuda and self._fused_head_expected(rays_o, auds):
+                    ind_index = idx                 # the fused training kernels pick the row themselves (train_head.head_forward)
+                else:
+                    ind_code = torch.index_select(self.individual_codes, 0, idx.long())
             else:
                 ind_code = self.individual_codes[index if self.training else 0]
 
         results = {}
         if self.training:
             head = self._head_training(rays_o, rays_d, nears, fars, enc_a, ind_code, eye, perturb, force_all_rays, dt_gamma, max_steps,
-                                       wait_for=audio_side, box=box)
+                                       wait_for=audio_side, box=box, ind_index=ind_index)
             nears, fars = head["nears"], head["fars"]
             results["weights_sum"], results["ambient"] = head["weights_sum"], head["ambient"]
         else:

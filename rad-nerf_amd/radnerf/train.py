@@ -296,11 +296,30 @@ class Trainer:
                 m.update_extra_state()
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=True)
-        with _join_in_optimizer(self.optimizer):
-            _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
-            loss.backward()
-            self.optimizer.step()
+        m._sample_budget = self._device_budget(m)
+        try:
+            with _join_in_optimizer(self.optimizer):
+                _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
+                loss.backward()
+                self.optimizer.step()
+        finally:
+            m._sample_budget = None
         return loss.detach()
+
+    def _device_budget(self, m):
+        """(device int32 budget, row capacity) for the renderer's one-launch marcher, or None (first window, CPU).  The budget is
+        raymarching.py:226-229's aligned running average; the device copy is rewritten only when it moves (every 16 steps)."""
+        dev = next(m.parameters()).device
+        if m.mean_count <= 0 or dev.type != "cuda":
+            return None
+        budget = int(m.mean_count)
+        budget += 128 - budget % 128
+        held = getattr(self, "_budget_held", None)
+        if held is None or held[0] != budget or held[1].device != dev:
+            t = held[1] if held is not None and held[1].device == dev else torch.zeros(1, dtype=torch.int32, device=dev)
+            t.fill_(budget)
+            self._budget_held = held = (budget, t)
+        return held[1], budget
 
 
 class _join_in_optimizer:

@@ -31,6 +31,9 @@ class HeadGradsT(C.Structure):
 
 _SIGS = {
     "rn_train_head_pack": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_train_head_pack_row": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "rn_train_head_weight_grads_row": [C.POINTER(NerfWeightsT), _ptr, _ptr, _ptr, _ptr, _u32, _u32, _ptr, _ptr, C.POINTER(HeadGradsT), _ptr,
+                                       _ptr],
     "rn_train_head_forward": [_ptr, _ptr, _u32, _ptr, C.POINTER(GridT), C.POINTER(GridT), _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                               _ptr, _ptr],
     "rn_train_head_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -81,7 +84,7 @@ class _HeadTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyzs, dirs, enc_a, eye, ind_code, m_dev, meta, table_x, table_w, *ws):
-        enc_x, enc_w, bound = meta
+        enc_x, enc_w, bound, ind_index = meta
         dev = xyzs.device
         M = xyzs.shape[0]
         xyzs, dirs = xyzs.contiguous(), dirs.contiguous()
@@ -89,13 +92,22 @@ class _HeadTrain(torch.autograd.Function):
         audio_dim, has_eye, ind_dim = ws[0].shape[1] - 32, ws[3].shape[1] - 64, ws[6].shape[1] - 80
         enc_a_c = enc_a.reshape(-1).contiguous().float()
         eye_c = eye.reshape(-1).contiguous().float() if has_eye else None
-        ind_c = ind_code.reshape(-1).contiguous().float() if ind_dim else None
+        if ind_index is not None:       # ind_code is the TABLE individual_codes; the row is picked on the device (no index_select)
+            ind_c = ind_code.detach().contiguous()
+            assert ind_dim and ind_c.dtype == torch.float32 and ind_c.dim() == 2 and ind_c.shape[1] == ind_dim
+            ind_index = ind_index.reshape(-1)[:1].contiguous()
+            assert ind_index.dtype == torch.int64 and ind_index.is_cuda
+        else:
+            ind_c = ind_code.reshape(-1).contiguous().float() if ind_dim else None
         tx, tw = hip.aligned(table_x.detach(), 64), hip.aligned(table_w.detach(), 64)
         nw = _weights_desc(ws, audio_dim, has_eye, ind_dim)
         gx, gw = _grid_desc(enc_x, tx), _grid_desc(enc_w, tw)
         s = hip.stream()
         image = torch.empty(int(_lib.rn_train_head_image_floats()), dtype=torch.float32, device=dev)
-        hip.call("rn_train_head_pack", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), hip.ptr(image), s)
+        if ind_index is not None:
+            hip.call("rn_train_head_pack_row", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), hip.ptr(ind_index), hip.ptr(image), s)
+        else:
+            hip.call("rn_train_head_pack", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), hip.ptr(image), s)
         work = torch.empty(int(_lib.rn_train_head_workspace_floats(M)), dtype=torch.float32, device=dev)
         # one block for the outputs.  Rows past the live count are not written: they belong to no ray, so the compositor never
         # reads them and the backward kernel skips them (RN_TRAIN_HEAD_ZERO=1 zero-fills the block, for tools that look at all rows)
@@ -110,9 +122,11 @@ class _HeadTrain(torch.autograd.Function):
             hip.call("rn_train_head_forward", hip.ptr(xyzs), hip.ptr(dirs), M, hip.ptr(m_dev), C.byref(gx), C.byref(gw), hip.ptr(image),
                      float(bound), sigmas.data_ptr(), rgbs.data_ptr(), ambient.data_ptr(), amb_abs.data_ptr(), xn.data_ptr(), wn.data_ptr(),
                      hip.ptr(work), s)
+        ctx.set_materialize_grads(False)      # an output nobody differentiates (ambient) costs no [M, 2] memset
         ctx.save_for_backward(image, work, out, m_dev, tx, tw, enc_a_c, eye_c, ind_c, *ws)
         ctx.meta = (enc_x, enc_w, M, audio_dim, has_eye, ind_dim, enc_a.shape, None if eye is None else eye.shape,
                     None if ind_code is None else ind_code.shape, table_x.dtype)
+        ctx.ind_index = ind_index
         return sigmas, rgbs, ambient, amb_abs
 
     @staticmethod
@@ -140,7 +154,11 @@ class _HeadTrain(torch.autograd.Function):
         grads = [torch.empty_like(w) for w in ws]
         g_enc_a = torch.empty(audio_dim, dtype=torch.float32, device=dev)
         g_eye = torch.empty(1, dtype=torch.float32, device=dev) if has_eye else None
-        g_ind = torch.empty(ind_dim, dtype=torch.float32, device=dev) if ind_dim else None
+        ind_index = ctx.ind_index
+        if ind_index is not None:       # the whole gradient table of individual_codes, written by the constants' launch
+            g_ind = torch.empty(ind_shape, dtype=torch.float32, device=dev)
+        else:
+            g_ind = torch.empty(ind_dim, dtype=torch.float32, device=dev) if ind_dim else None
         if M:
             g_feat = torch.empty(2, 16, M, 2, dtype=torch.float32, device=dev)
             hip.call("rn_train_head_backward", hip.ptr(g_sigma), hip.ptr(g_rgb), hip.ptr(g_ambient), hip.ptr(g_amb_abs), rgbs.data_ptr(),
@@ -173,8 +191,12 @@ class _HeadTrain(torch.autograd.Function):
             (hg.amb_w0, hg.amb_w1, hg.amb_w2, hg.sig_w0, hg.sig_w1, hg.sig_w2, hg.col_w0, hg.col_w1) = [g.data_ptr() for g in grads]
             hg.enc_a, hg.eye, hg.ind_code = g_enc_a.data_ptr(), hip.ptr(g_eye), hip.ptr(g_ind)
             wsp = hip.workspace(int(_lib.rn_train_head_wgrad_workspace()), dev)
-            hip.call("rn_train_head_weight_grads", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), M, hip.ptr(m_dev), hip.ptr(work),
-                     C.byref(hg), hip.ptr(wsp), s)
+            if ind_index is not None:
+                hip.call("rn_train_head_weight_grads_row", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), hip.ptr(ind_index),
+                         int(ind_shape[0]), M, hip.ptr(m_dev), hip.ptr(work), C.byref(hg), hip.ptr(wsp), s)
+            else:
+                hip.call("rn_train_head_weight_grads", C.byref(nw), hip.ptr(enc_a_c), hip.ptr(eye_c), hip.ptr(ind_c), M, hip.ptr(m_dev), hip.ptr(work),
+                         C.byref(hg), hip.ptr(wsp), s)
             if side is None:
                 g_tx, g_tw = zero_table_gradient(enc_x, tx), torch.zeros_like(tw)
                 gx, gw = _grid_desc(enc_x, tx), _grid_desc(enc_w, tw)
@@ -316,13 +338,19 @@ def grid_scatter(jobs, M, m_dev):
     hip.call("rn_grid_scatter_jobs", arr, len(jobs), M, hip.ptr(m_dev), hip.ptr(ws), ws_bytes, s)
 
 
-def head_forward(model, xyzs, dirs, enc_a, ind_code, eye, m_dev=None):
+def head_forward(model, xyzs, dirs, enc_a, ind_code, eye, m_dev=None, ind_index=None):
     """-> (sigma, rgb, ambient, ambient_abs): NeRFNetwork.forward + `ambient.abs().sum(-1)` (nerf/renderer.py:216) through the
-    fused training kernels.  m_dev: optional int32 device scalar, the number of live sample rows (the marcher's counter)."""
+    fused training kernels.  m_dev: optional int32 device scalar, the number of live sample rows (the marcher's counter).
+    ind_index (int64 device tensor, one element) instead of ind_code: the code is model.individual_codes[ind_index], picked by the
+    kernels; the gradient of individual_codes comes back whole from the backward pass (no index_select / memset / index_add)."""
     ws = _weights_of(model)
-    ind = ind_code if model.individual_dim > 0 else None
+    ind = None
+    if model.individual_dim > 0:
+        ind = model.individual_codes if ind_index is not None else ind_code
+    else:
+        ind_index = None
     e = eye if model.exp_eye else None
-    return _HeadTrain.apply(xyzs, dirs, enc_a, e, ind, m_dev, (model.encoder, model.encoder_ambient, float(model.bound)),
+    return _HeadTrain.apply(xyzs, dirs, enc_a, e, ind, m_dev, (model.encoder, model.encoder_ambient, float(model.bound), ind_index),
                             model.encoder.embeddings, model.encoder_ambient.embeddings, *ws)
 
 
@@ -358,12 +386,15 @@ class _HeadLoss(torch.autograd.Function):
         ctx.save_for_backward(out)
         ctx.N = N
         ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)          # no [N, 3] memset for pred's (never defined) gradient
         return loss.view(()), pred
 
     @staticmethod
     def backward(ctx, g, _g_pred):
         (out,) = ctx.saved_tensors
         N = ctx.N
+        if g is None:
+            return (None,) * 7
         scaled = out[3 * N:8 * N] * g            # one kernel for the three gradients
         return scaled[0:3 * N].view(N, 3), scaled[3 * N:4 * N], scaled[4 * N:5 * N], None, None, None, None
 

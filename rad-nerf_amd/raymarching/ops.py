@@ -302,6 +302,7 @@ class _composite_rays_train(Function):
                  hip.ptr(ambient_sum), hip.ptr(depth), hip.ptr(image), hip.stream())
         ctx.save_for_backward(sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, image)
         ctx.dims = (M, N, T_thresh)
+        ctx.set_materialize_grads(False)      # depth's gradient is ignored (raymarching.py:324): no memset for it when it is undefined
         return weights_sum, ambient_sum, depth, image
 
     @staticmethod
@@ -313,8 +314,11 @@ class _composite_rays_train(Function):
         # zero-initialised: samples that belong to no ray (rows past the counter) receive no gradient -- one memset for the three
         flat = torch.zeros(M * 5, dtype=_f32, device=sigmas.device)
         grad_sigmas, grad_ambient, grad_rgbs = flat[:M], flat[M:2 * M], flat[2 * M:].view(M, 3)
-        grad_weights_sum, grad_ambient_sum = grad_weights_sum.contiguous(), grad_ambient_sum.contiguous()
-        grad_image = grad_image.contiguous()
+        if grad_weights_sum is None and grad_ambient_sum is None and grad_image is None:
+            return grad_sigmas, grad_rgbs, grad_ambient, None, None, None
+        zeros = lambda g, *shape: torch.zeros(*shape, dtype=_f32, device=sigmas.device) if g is None else g.contiguous()  # noqa: E731
+        grad_weights_sum, grad_ambient_sum = zeros(grad_weights_sum, N), zeros(grad_ambient_sum, N)
+        grad_image = zeros(grad_image, N, 3)
         hip.call("rn_composite_rays_train_backward", hip.ptr(grad_weights_sum, _f32),
                  hip.ptr(grad_ambient_sum, _f32), hip.ptr(grad_image, _f32), hip.ptr(sigmas),
                  hip.ptr(rgbs), hip.ptr(ambient), hip.ptr(deltas), hip.ptr(rays), hip.ptr(weights_sum),

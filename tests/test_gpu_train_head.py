@@ -148,6 +148,45 @@ def test_fused_head_live_count_bounds_the_rows(hiplib, monkeypatch):
         assert float((g_a[name] - g_b[name]).abs().max()) / scale < 1e-4, name
 
 
+def test_individual_code_row_picked_on_the_device(hiplib):
+    """head_forward(ind_index=...) == head_forward(ind_code=individual_codes[index]): same outputs, same gradients, and the gradient of
+    individual_codes comes back whole -- the picked row filled, zeros everywhere else -- from the constants' launch (what
+    index_select's backward builds with a memset and an index_add)."""
+    scene = _scene(32)
+    m = scene.model
+    m.train()
+    from radnerf import train_head
+    M = 3000
+    xyzs, dirs, enc_a, eye, gen = _samples(M, 9)
+    g = [torch.randn(M, device="cuda", generator=gen), torch.randn(M, 3, device="cuda", generator=gen), torch.randn(M, device="cuda", generator=gen)]
+    with torch.no_grad():
+        m.individual_codes.normal_(0, 0.3)
+    row = 5
+    idx = torch.tensor([row], dtype=torch.int64, device="cuda")
+
+    def run(**how):
+        for p in m.parameters():
+            p.grad = None
+        s, c, a, aa = train_head.head_forward(m, xyzs, dirs, enc_a, how.get("ind_code"), eye, ind_index=how.get("ind_index"))
+        ((s * g[0]).sum() + (c * g[1]).sum() + (aa * g[2]).sum()).backward()
+        return (s.detach().clone(), c.detach().clone(), aa.detach().clone()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    out_a, g_a = run(ind_index=idx)
+    out_b, g_b = run(ind_code=torch.index_select(m.individual_codes, 0, idx))
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+    ga, gb = g_a["individual_codes"], g_b["individual_codes"]
+    assert ga.shape == m.individual_codes.shape and torch.equal(ga, gb) and float(ga[row].abs().max()) > 0
+    assert float(ga.abs().sum()) == float(ga[row].abs().sum())            # every other row is exactly zero
+    assert g_a.keys() == g_b.keys()
+    for name in g_b:
+        if "embeddings" in name:                 # the tables' scatter adds in another order from launch to launch
+            scale = float(g_b[name].abs().max()) + 1e-12
+            assert float((g_a[name] - g_b[name]).abs().max()) / scale < 1e-5, name
+        else:
+            assert torch.equal(g_a[name], g_b[name]), name
+
+
 @pytest.mark.parametrize("points", ["rays", "coincident"])
 @pytest.mark.parametrize("D", [2, 3])
 def test_line_keyed_scatter_matches_the_operator_scatter(hiplib, monkeypatch, D, points):

@@ -31,13 +31,18 @@ def main():
     torch.cuda.synchronize()
     assert trainer.global_step % 16 != 0          # not a refresh step
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True, with_stack=bool(os.environ.get("RN_FILL_STACKS"))) as prof:
         trainer.step(stream.batch())
         torch.cuda.synchronize()
     ev = [e for e in prof.events() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
     ev.sort(key=lambda e: e.time_range.start)
     rows = [dict(name=e.name[:110], us=round(e.time_range.elapsed_us(), 1)) for e in ev]
     kernels = [r for r in rows if not r["name"].startswith("Memcpy") and not r["name"].startswith("Memset")]
+    if os.environ.get("RN_FILL_STACKS"):       # which Python line asked for each memset-like kernel
+        for e in prof.events():
+            if e.name in ("aten::fill_", "aten::zero_") and e.input_shapes:
+                where = [fr for fr in (e.stack or []) if "/rad-nerf_amd/" in fr or "bench.py" in fr][:2]
+                print("fill", e.input_shapes[0], where, file=sys.stderr)
     print(json.dumps(dict(launches=len(rows), kernels=len(kernels), gpu_us=round(sum(r["us"] for r in rows), 1),
                           samples=int(scene.model.step_counter[(scene.model.local_step - 1) % 16, 0]), sequence=rows), indent=1))
 
