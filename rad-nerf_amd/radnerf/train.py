@@ -211,6 +211,15 @@ def train_step(model, data, opt, global_step=0, iters=200000, lambda_amb=0.1, am
     return pred, rgb, loss
 
 
+def _backward(loss):
+    """loss.backward(); a loss of the fused head-loss kernel hands its ready-made input gradients to autograd directly."""
+    if getattr(loss, "_rn_direct", None) is not None:
+        from . import train_head
+        train_head.backward(loss)
+    else:
+        loss.backward()
+
+
 class SyntheticTrainStream:
     """Batches of `n_rays` random pixels of a SyntheticScene frame with the scene's own frozen render as target
     (SURVEY 8(d) config 2); everything stays on the device."""
@@ -300,7 +309,7 @@ class Trainer:
         try:
             with _join_in_optimizer(self.optimizer):
                 _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
-                loss.backward()
+                _backward(loss)
                 self.optimizer.step()
         finally:
             m._sample_budget = None
@@ -390,7 +399,7 @@ class GraphedTrainer(Trainer):
         try:
             with torch.cuda.graph(g), _join_in_optimizer(self.optimizer):   # a private memory pool per graph: cached graphs never alias each other
                 _, _, loss = train_step(m, self._static, self.opt, amb_weight=self._amb_weight)
-                loss.backward()
+                _backward(loss)
                 self.optimizer.step()
         finally:
             m._static_counter = None
@@ -414,7 +423,7 @@ class GraphedTrainer(Trainer):
             self.optimizer.zero_grad(set_to_none=True)
             with _join_in_optimizer(self.optimizer):
                 _, _, loss = train_step(m, data, self.opt, self.global_step, self.iters, self.lambda_amb)
-                loss.backward()
+                _backward(loss)
                 self.optimizer.step()
             return loss.detach()
         budget = int(m.mean_count)

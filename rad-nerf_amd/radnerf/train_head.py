@@ -385,12 +385,13 @@ class _HeadLoss(torch.autograd.Function):
                  g_ws.data_ptr(), g_amb.data_ptr(), hip.stream())
         ctx.save_for_backward(out)
         ctx.N = N
-        ctx.mark_non_differentiable(pred)
+        grads = out[3 * N:8 * N]
+        ctx.mark_non_differentiable(pred, grads)
         ctx.set_materialize_grads(False)          # no [N, 3] memset for pred's (never defined) gradient
-        return loss.view(()), pred
+        return loss.view(()), pred, grads
 
     @staticmethod
-    def backward(ctx, g, _g_pred):
+    def backward(ctx, g, _g_pred, _g_grads):
         (out,) = ctx.saved_tensors
         N = ctx.N
         if g is None:
@@ -411,7 +412,21 @@ def head_loss(image, weights_sum, ambient, bg, target, face, w_amb):
         if t.dim() == 2 and t.stride(1) != 1:
             t = t.contiguous()
         return t
-    return _HeadLoss.apply(image, weights_sum, ambient, rows(bg, 3), rows(target, 3), rows(face, 1), w_amb.reshape(1))
+    loss, pred, grads = _HeadLoss.apply(image, weights_sum, ambient, rows(bg, 3), rows(target, 3), rows(face, 1), w_amb.reshape(1))
+    # d loss / d (image, weights_sum, ambient) were written by the same kernel: backward(loss) below hands them to autograd as
+    # they are instead of going through `ones_like(loss)` and a multiplication by it (two launches)
+    N = image.shape[0]
+    loss._rn_direct = ((image, weights_sum, ambient), (grads[0:3 * N].view(N, 3), grads[3 * N:4 * N], grads[4 * N:5 * N]))
+    return loss, pred
+
+
+def backward(loss):
+    """loss.backward() for a loss of head_loss(): its input gradients exist already (upstream gradient 1)."""
+    direct = getattr(loss, "_rn_direct", None)
+    if direct is None or not all(t.requires_grad for t in direct[0]):
+        loss.backward()
+    else:
+        torch.autograd.backward(direct[0], direct[1])
 
 
 def batch_gather(table, idx, widths):

@@ -262,6 +262,15 @@ def test_head_loss_kernel_matches_the_pytorch_expression(hiplib):
     assert torch.allclose(got[2], image.grad, rtol=1e-5, atol=1e-10)
     assert torch.allclose(got[3], ws.grad, rtol=2e-5, atol=1e-9)
     assert torch.allclose(got[4], amb.grad, rtol=1e-5, atol=1e-10)
+    # train_head.backward(loss) == loss.backward(): the kernel's own input gradients handed to autograd as they are
+    image.grad = ws.grad = amb.grad = None
+    loss, _ = train_head.head_loss(image, ws, amb, bg, target, face, w_amb)
+    loss.backward()
+    ref = (image.grad.clone(), ws.grad.clone(), amb.grad.clone())
+    image.grad = ws.grad = amb.grad = None
+    loss, _ = train_head.head_loss(image, ws, amb, bg, target, face, w_amb)
+    train_head.backward(loss)
+    assert torch.equal(image.grad, ref[0]) and torch.equal(ws.grad, ref[1]) and torch.equal(amb.grad, ref[2])
 
 
 def _train_losses(monkeypatch, head, steps=6):
