@@ -236,8 +236,8 @@ int rn_blend_frame(float *image, const float *weights_sum, const float *bg, floa
  *   rn_occupancy_update      tmp = sigmas * density_scale; 6-neighbour max in morton space (raymarching.cu:304-341); where
  *                            grid >= 0 and tmp >= 0: grid = max(grid * decay, tmp); stats[0] = mean(max(grid, 0)) (summed in
  *                            double), stats[1] = min(stats[0], density_thresh); bitfield = packbits(grid, stats[1]).
- *                            workspace: rn_occupancy_workspace(C, H) bytes, ZEROED once by the caller (an arrival counter
- *                            lives in it; the kernel leaves it zero).  Nothing is read back by the host.
+ *                            workspace: rn_occupancy_workspace(C, H) bytes (per-workgroup partial sums; a one-workgroup
+ *                            launch adds them up).  Nothing is read back by the host.
  *   rn_mark_untrained_grid   grid[c, cell] = -1 for cells no camera sees: poses [n, 4, 4] (pose_stride = 16 floats) or
  *                            [n, 3, 4] (12) cam2world, intrinsics as the Python floats fx, fy, cx, cy.
  *   rn_torso_grid_points     xys[H*H, 2] for element i = (column i % H, row i / H) (the transposed index of renderer.py:472);

@@ -11,7 +11,7 @@
 //   * every read and write of the grid is coalesced.
 // Per refresh:  k_occ_points (cell centre + jitter)  ->  fused network kernel, sigma branch only (rn_nerf_fused_forward with
 // rgbs = NULL)  ->  k_occ_update (6-neighbour dilation in morton space, decayed running max, per-workgroup partial sums of
-// max(grid, 0); the LAST workgroup to finish adds the partials up in index order and publishes mean and threshold)  ->
+// max(grid, 0))  ->  k_occ_mean (one workgroup adds the partials up in index order and publishes mean and threshold)  ->
 // k_occ_pack (bit i of byte n = grid[8 n + i] > threshold, threshold read from device memory: no host read-back).
 // The 2-D torso grid (128^2 alphas): k_torso_points -> rn_torso_fused with the occupancy test disabled -> k_torso_update
 // (5 x 5 max pool with -inf padding, decayed running max, mean; one workgroup, the whole grid staged in LDS).
@@ -61,12 +61,11 @@ k_occ_points(uint32_t C, uint32_t H, CascadeConsts cc, const float *__restrict__
 }
 
 // ---- dilation + decayed max + mean (renderer.py:438-446, raymarching.cu:304-341) ---------------------------------
-// scratch: double partial[blocks] | uint32 arrivals | float stats[2] = {mean_density, threshold}
+// scratch: double partial[blocks]; stats[2] = {mean_density, threshold} come from k_occ_mean
 __global__ void __launch_bounds__(kOccBlock)
 k_occ_update(const float *__restrict__ sigmas, float density_scale, float *__restrict__ grid, uint32_t C, uint32_t H, float decay,
-             float density_thresh, double *__restrict__ partial, uint32_t *__restrict__ arrivals, float *__restrict__ stats) {
+             double *__restrict__ partial) {
     __shared__ double red[kOccBlock / kWave];
-    __shared__ bool is_last;
     const uint32_t H3 = H * H * H, total = C * H3;
     const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
     float clamped = 0.0f;
@@ -98,18 +97,18 @@ k_occ_update(const float *__restrict__ sigmas, float density_scale, float *__res
         double b = 0.0;
         for (int w = 0; w < kOccBlock / kWave; w++) b += red[w];
         partial[blockIdx.x] = b;
-        __threadfence();                                            // release: the partial before the arrival count
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // keep the wait behind the write-back (the compiler may drop its own)
-        is_last = atomicAdd(arrivals, 1u) == gridDim.x - 1;
     }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();                                                // acquire: every other workgroup's partial
+}
+
+// The partial sums added up in index order -> mean and threshold.  A launch of its own (one workgroup): the "last workgroup to
+// arrive adds them up" form needs a release fence per workgroup, and on this chip that fence is a write-back of the XCD's L2 --
+// 8 192 of them made k_occ_update 243 us long; the kernel boundary orders the partials for free (k_occ_update 34 us + this).
+__global__ void __launch_bounds__(kOccBlock)
+k_occ_mean(const double *__restrict__ partial, uint32_t blocks, uint32_t total, float density_thresh, float *__restrict__ stats) {
+    __shared__ double red[kOccBlock / kWave];
     double acc = 0.0;
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += kOccBlock)
-        acc += __hip_atomic_load(&partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t b = threadIdx.x; b < blocks; b += kOccBlock) acc += partial[b];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -118,7 +117,6 @@ k_occ_update(const float *__restrict__ sigmas, float density_scale, float *__res
         const float mean = (float)(sum / (double)total);
         stats[0] = mean;
         stats[1] = fminf(mean, density_thresh);                     // density_thresh = min(mean_density, self.density_thresh)
-        *arrivals = 0;                                              // ready for the next refresh
     }
 }
 
@@ -257,7 +255,7 @@ extern "C" {
 
 size_t rn_occupancy_workspace(uint32_t C, uint32_t H) {
     const size_t blocks = div_up(C * H * H * H, kOccBlock);
-    return blocks * sizeof(double) + 64;              // partial sums | arrival counter (kept zero between calls) | pad
+    return blocks * sizeof(double) + 64;              // partial sums | pad
 }
 
 int rn_occupancy_points(uint32_t C, uint32_t H, float bound, const float *noise, uint32_t seed, float *xyzs, rn_stream_t stream) {
@@ -275,10 +273,9 @@ int rn_occupancy_update(const float *sigmas, float density_scale, float *density
     RN_REQUIRE(((uintptr_t)density_grid & 15u) == 0 && ((uintptr_t)workspace & 7u) == 0, "occupancy_update: alignment");
     const uint32_t total = C * H * H * H, blocks = div_up(total, kOccBlock);
     double *partial = static_cast<double *>(workspace);
-    uint32_t *arrivals = reinterpret_cast<uint32_t *>(partial + blocks);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_occ_update, dim3(blocks), dim3(kOccBlock), 0, s, sigmas, density_scale, density_grid, C, H, decay,
-                       density_thresh, partial, arrivals, stats);
+    hipLaunchKernelGGL(k_occ_update, dim3(blocks), dim3(kOccBlock), 0, s, sigmas, density_scale, density_grid, C, H, decay, partial);
+    hipLaunchKernelGGL(k_occ_mean, dim3(1), dim3(kOccBlock), 0, s, partial, blocks, total, density_thresh, stats);
     hipLaunchKernelGGL(k_occ_pack, dim3(div_up(total / 8, kOccBlock)), dim3(kOccBlock), 0, s, density_grid, total / 8, stats, bitfield);
     return check_launch("occupancy_update");
 }

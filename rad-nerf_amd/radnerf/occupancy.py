@@ -45,7 +45,7 @@ def exported_symbols():
 
 
 class _Scratch:
-    """Per-model buffers of the refresh: probe points, sigmas, statistics, the zeroed arrival workspace."""
+    """Per-model buffers of the refresh: probe points, sigmas, statistics, the partial-sum workspace."""
 
     def __init__(self, model):
         dev = model.density_bitfield.device
