@@ -365,7 +365,8 @@ __global__ void k_march_train_counter(int32_t *counter, const uint32_t *block_su
 // rn_near_far_from_aabb + a memset of the counters + rn_march_rays_train_budget's three kernels do in five launches; at 4 096
 // rays these are 16 workgroups whose time is the length of one ray's walk, so the launches cost more than the work.
 // The counts cross workgroups inside the launch: workgroup b stores (launch tag, its sample count) as one 64-bit word with an
-// agent-scope release store, and every workgroup waits until all n_blocks words carry this launch's tag (they are its barrier
+// agent-scope atomic store (relaxed: the word is the whole message -- a release / acquire pair here would be an L2 write-back and
+// an L2 invalidate per workgroup and per poll), and every workgroup waits until all n_blocks words carry this launch's tag (they are its barrier
 // and its scan at once: the sum of the words before b is b's offset, the sum of all is the step's sample count).  The tag is a
 // launch epoch kept in `state` (zero-initialised once by the caller, then owned by these launches): read by every workgroup
 // before it stores its word, bumped by workgroup 0 after it has seen all words -- so nobody can read the new value early.
@@ -414,17 +415,17 @@ k_march_train_step(const float *__restrict__ rays_o, const float *__restrict__ r
     }
     const uint32_t sum = block_reduce_sum(num_steps, lds);
     if (threadIdx.x == 0)
-        __hip_atomic_store(&words[blockIdx.x], ((unsigned long long)tag << 32) | sum, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&words[blockIdx.x], ((unsigned long long)tag << 32) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // barrier + scan: every workgroup's word of THIS launch
     uint32_t part = 0, all = 0;
     for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock) {
-        unsigned long long w = __hip_atomic_load(&words[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long w = __hip_atomic_load(&words[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t polls = 0;
         while ((uint32_t)(w >> 32) != tag) {
             __builtin_amdgcn_s_sleep(1);
             if (++polls > kStepPolls) { stalled = 1u; break; }
-            w = __hip_atomic_load(&words[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            w = __hip_atomic_load(&words[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint32_t cnt = (uint32_t)(w & 0xffffffffull);
         all += cnt;
