@@ -118,13 +118,16 @@ int rn_march_rays_train_budget(const float *rays_o, const float *rays_d, const u
  * The workgroups exchange their counts inside the launch, so all ceil(N / 256) of them must be resident together:
  * N <= 256 * (number of CUs), else RN_ERR_INVALID_ARG.  `state`: rn_march_rays_train_step_state(N) bytes, 8-byte aligned,
  * zeroed ONCE by the caller and then left to these launches (word 0 = launch epoch, word 1 = launches whose exchange
- * timed out -- must stay 0; such a step reports counter[0] = 0 and marks every ray empty).  noises may be NULL (no jitter). */
+ * timed out -- must stay 0; such a step reports counter[0] = 0 and marks every ray empty).  Jitter of the first sample
+ * (raymarching.cu:392): noises [N] uniform [0,1) as the reference draws them, or noises == NULL and jitter_seed != 0: a
+ * counter-based hash of (jitter_seed, launch epoch, ray) -- a new draw per launch without a launch of its own; both NULL / 0:
+ * no jitter. */
 size_t rn_march_rays_train_step_state(uint32_t N);
 int rn_march_rays_train_step(const float *rays_o, const float *rays_d, const uint8_t *grid, const float *aabb,
                              float min_near, float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C,
                              uint32_t H, uint32_t M, const int32_t *M_dev, const float *noises, float *nears,
                              float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
-                             void *state, rn_stream_t stream);
+                             void *state, uint32_t jitter_seed, rn_stream_t stream);
 /* raymarching.h:15  march_rays_train_backward   (raymarching.cu:535-593) */
 int rn_march_rays_train_backward(const float *grad_xyzs, const float *grad_dirs, const int32_t *rays,
                                  const float *deltas, uint32_t N, uint32_t M, float *grad_rays_o,

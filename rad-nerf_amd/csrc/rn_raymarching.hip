@@ -380,6 +380,11 @@ __global__ void k_march_train_counter(int32_t *counter, const uint32_t *block_su
 constexpr uint32_t kStepPolls = 1u << 20;
 constexpr uint32_t kRecSteps = 32;
 
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32" finaliser (as rn_occupancy.hip's jitter)
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
 template <bool RECORD>
 __global__ void __launch_bounds__(kBlock)
 k_march_train_step(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid,
@@ -387,7 +392,7 @@ k_march_train_step(const float *__restrict__ rays_o, const float *__restrict__ r
                    uint32_t C, uint32_t H, uint32_t M, const int32_t *__restrict__ M_dev, const float *__restrict__ noises,
                    float *__restrict__ nears, float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
                    float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *__restrict__ counter, uint32_t *state,
-                   unsigned long long *words) {
+                   unsigned long long *words, uint32_t jitter_seed) {
     __shared__ uint32_t lds[kBlock / kWave];
     __shared__ uint32_t wave_tot[kBlock / kWave];
     __shared__ uint32_t stalled;
@@ -408,7 +413,12 @@ k_march_train_step(const float *__restrict__ rays_o, const float *__restrict__ r
         Dda s;
         s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid, far);
         t0 = near;
-        t0 += clampf(t0 * dt_gamma, s.dt_min, s.dt_max) * (noises ? noises[n] : 0.0f);  // :392
+        // :392 -- the jitter: the caller's uniform numbers (torch.rand in the reference), or (jitter_seed != 0) 24 random bits
+        // of a counter-based hash of (seed, launch epoch, ray): a launch less per step, a new draw per launch even when replayed
+        float u = 0.0f;
+        if (noises) u = noises[n];
+        else if (jitter_seed) u = (float)(mix32(mix32(n) ^ mix32(jitter_seed + tag)) >> 8) * (1.0f / 16777216.0f);
+        t0 += clampf(t0 * dt_gamma, s.dt_min, s.dt_max) * u;
         float t = t0;
         if constexpr (RECORD) num_steps = s.walk_record(t, max_steps, t_rec + threadIdx.x, kBlock);
         else num_steps = s.walk<false>(t, max_steps, nullptr, nullptr, nullptr);
@@ -682,7 +692,7 @@ static int step_cus() {
 int rn_march_rays_train_step(const float *rays_o, const float *rays_d, const uint8_t *grid, const float *aabb, float min_near,
                              float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                              const int32_t *M_dev, const float *noises, float *nears, float *fars, float *xyzs, float *dirs,
-                             float *deltas, int32_t *rays, int32_t *counter, void *state, rn_stream_t stream) {
+                             float *deltas, int32_t *rays, int32_t *counter, void *state, uint32_t jitter_seed, rn_stream_t stream) {
     if (N == 0) return RN_OK;
     RN_REQUIRE(rays_o && rays_d && grid && aabb && nears && fars && xyzs && dirs && deltas && rays && counter && state,
                "march_rays_train_step: null pointer");
@@ -695,10 +705,10 @@ int rn_march_rays_train_step(const float *rays_o, const float *rays_d, const uin
     unsigned long long *words = reinterpret_cast<unsigned long long *>(st + 2);
     if (max_steps <= kRecSteps)
         hipLaunchKernelGGL(k_march_train_step<true>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, grid, aabb, min_near,
-                           bound, dt_gamma, max_steps, N, C, H, M, M_dev, noises, nears, fars, xyzs, dirs, deltas, rays, counter, st, words);
+                           bound, dt_gamma, max_steps, N, C, H, M, M_dev, noises, nears, fars, xyzs, dirs, deltas, rays, counter, st, words, jitter_seed);
     else
         hipLaunchKernelGGL(k_march_train_step<false>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, grid, aabb, min_near,
-                           bound, dt_gamma, max_steps, N, C, H, M, M_dev, noises, nears, fars, xyzs, dirs, deltas, rays, counter, st, words);
+                           bound, dt_gamma, max_steps, N, C, H, M, M_dev, noises, nears, fars, xyzs, dirs, deltas, rays, counter, st, words, jitter_seed);
     return check_launch("march_rays_train_step");
 }
 

@@ -205,8 +205,10 @@ class NeRFRenderer(nn.Module):
             from raymarching.ops import march_rays_train_step
             self.local_step += 1
             fused_head = th is not None and th.usable(self, rays_o, enc_a)
+            import os
+            jitter = "hash" if (perturb and os.environ.get("RN_TRAIN_NOISE", "hash") == "hash") else perturb
             nears, fars, xyzs, dirs, deltas, rays = march_rays_train_step(rays_o, rays_d, box, self.min_near, self.bound, self.density_bitfield,
-                                                                          self.cascade, self.grid_size, counter, budget[0], budget[1], perturb,
+                                                                          self.cascade, self.grid_size, counter, budget[0], budget[1], jitter,
                                                                           dt_gamma, max_steps, not fused_head)
             return self._head_network(xyzs, dirs, deltas, rays, nears, fars, enc_a, ind_code, eye, counter, wait_for, ind_index)
         counter.zero_()

@@ -431,7 +431,9 @@ class GraphedTrainer(Trainer):
         step = self.capacity_step
         if not (budget <= self._capacity <= budget + 2 * step):         # keep the capacity while the budget stays inside its window
             self._capacity = -(-(budget + step // 4) // step) * step
-        self._budget.fill_(budget)
+        if budget != getattr(self, "_budget_value", None):               # the running average moves every 16 steps, not every step
+            self._budget.fill_(budget)
+            self._budget_value = budget
         key = (self._capacity, tuple(data["rays_o"].shape))
         if key != self._key:
             hit = self._graphs.pop(key, None)
@@ -453,7 +455,10 @@ class GraphedTrainer(Trainer):
         if isinstance(v, (list, tuple)) and list(v) != self._static_index:
             self._static["index"].copy_(torch.tensor(v, dtype=torch.long))
             self._static_index = list(v)
-        self._amb_weight.fill_(min(self.global_step / self.iters, 1.0) * self.lambda_amb)
+        w_amb = min(self.global_step / self.iters, 1.0) * self.lambda_amb
+        if w_amb != getattr(self, "_amb_value", None):                   # constant once the ramp is over
+            self._amb_weight.fill_(w_amb)
+            self._amb_value = w_amb
         if isinstance(self.optimizer, HipAdam):
             self.optimizer.refresh_lr()             # a schedule may have rewritten param_groups[i]["lr"] since the last step
         self._graph.replay()

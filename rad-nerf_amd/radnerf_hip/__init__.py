@@ -36,7 +36,7 @@ _SIGNATURES = {
     "rn_march_rays_train_budget": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "rn_march_rays_train_step": [_ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                 _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+                                 _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr],
     "rn_march_rays_train_backward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_composite_rays_train_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr,
                                         _ptr],

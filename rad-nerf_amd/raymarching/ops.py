@@ -236,7 +236,8 @@ def step_marcher_supported(N, device):
 class _march_rays_train_step(Function):
     """A training step's marcher as ONE launch (rn_march_rays_train_step; not in the reference's surface): near / far against
     `aabb`, count pass, ordered slices, write pass, counters -- what near_far_from_aabb + `step_counter.zero_()` +
-    march_rays_train_budget do in five.  `step_counter` is SET to (samples, N).  `zeroed`: hand out zero-filled sample buffers
+    march_rays_train_budget do in five.  `step_counter` is SET to (samples, N).  perturb = "hash": the jitter comes from the
+    launch's own hash instead of a torch.rand launch.  `zeroed`: hand out zero-filled sample buffers
     (a network pass that visits every row of the capacity needs them; the fused training pass stops at step_counter[0], and
     every row below it is written by the launch).  Returns nears, fars, xyzs, dirs, deltas, rays."""
 
@@ -256,12 +257,14 @@ class _march_rays_train_step(Function):
             xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
         rays = torch.empty(N, 3, dtype=torch.int32, device=device)
         nf = torch.empty(2, N, dtype=_f32, device=device)
-        noises = torch.rand(N, dtype=_f32, device=device) if perturb else None
+        # perturb: False | True (torch.rand, what the reference draws) | "hash" (the launch's own counter-based hash: no launch)
+        noises = torch.rand(N, dtype=_f32, device=device) if (perturb and perturb != "hash") else None
+        seed = ((torch.initial_seed() & 0x7fffffff) | 1) if perturb == "hash" else 0
         state = _step_state(N, device)
         hip.call("rn_march_rays_train_step", hip.ptr(rays_o, _f32), hip.ptr(rays_d, _f32), hip.ptr(density_bitfield, torch.uint8),
                  hip.ptr(aabb, _f32), float(min_near), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), M,
                  hip.ptr(budget, torch.int32), hip.ptr(noises), hip.ptr(nf[0]), hip.ptr(nf[1]), hip.ptr(xyzs), hip.ptr(dirs), hip.ptr(deltas),
-                 hip.ptr(rays), hip.ptr(step_counter, torch.int32), hip.ptr(state), hip.stream())
+                 hip.ptr(rays), hip.ptr(step_counter, torch.int32), hip.ptr(state), seed, hip.stream())
         ctx.save_for_backward(rays, deltas)
         ctx.mark_non_differentiable(nf, rays)
         return nf[0], nf[1], xyzs, dirs, deltas, rays

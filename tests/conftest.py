@@ -20,6 +20,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _reproducible_training_jitter(monkeypatch):
+    """Tests that compare two runs of the training step draw the marcher's jitter with torch.rand (seeded by torch.manual_seed), as
+    the reference does; the product default is the marcher's own hash (one launch less), which draws anew on every launch.
+    test_gpu_train.py::test_step_marcher_hash_jitter_* and the launch-count test cover that form."""
+    monkeypatch.setenv("RN_TRAIN_NOISE", "torch")
+
+
 def _has_gpu():
     try:
         import torch

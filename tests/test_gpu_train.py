@@ -327,6 +327,39 @@ def test_one_launch_step_marcher_equals_the_five_launch_chain(hiplib, budget_fra
     assert bool(torch.isnan(x3[live:]).all()) and bool(torch.isnan(dl3[live:]).all())
 
 
+def test_step_marcher_hash_jitter_is_a_new_uniform_draw_per_launch(hiplib):
+    """perturb = "hash": the first sample of a ray is moved by u * dt with u from the launch's own counter-based hash (no
+    torch.rand launch).  With every cell occupied the first sample sits at near + u * dt, so u can be read back: uniform on
+    [0, 1), and a new draw per launch (the launch epoch is part of the hash)."""
+    from raymarching import ops
+    scene = _scene(64)
+    m, f = scene.model, scene.frame(0)
+    o, d = f["rays_o"].reshape(-1, 3).contiguous(), f["rays_d"].reshape(-1, 3).contiguous()
+    N = o.shape[0]
+    cap = N * scene.opt.max_steps
+    bt = torch.tensor([cap], dtype=torch.int32, device="cuda")
+    full = torch.full_like(m.density_bitfield, 255)
+
+    def run(perturb):
+        c = torch.zeros(2, dtype=torch.int32, device="cuda")
+        nears, _, x, dd, dl, r = ops.march_rays_train_step(o, d, m.aabb_train, m.min_near, m.bound, full, m.cascade, m.grid_size, c, bt, cap,
+                                                           perturb, scene.opt.dt_gamma, scene.opt.max_steps, True)
+        assert int(c[0]) == int(r[:, 2].sum()) and int(c[1]) == N
+        hit = r[:, 2] > 0
+        first = r[hit, 1].long()
+        return hit, (dl[first, 1] - dl[first, 0] - nears[hit]) / dl[first, 0]      # (t of the first sample - near) / dt
+    hit0, u0 = run(False)
+    assert int(hit0.sum()) > N // 2 and float(u0.abs().max()) < 1e-4
+    hit1, u1 = run("hash")
+    hit2, u2 = run("hash")
+    assert torch.equal(hit0, hit1) and torch.equal(hit0, hit2)
+    assert not torch.equal(u1, u2)                                                 # a new draw per launch
+    for u in (u1, u2):
+        assert float(u.min()) > -1e-4 and float(u.max()) < 1 + 1e-4
+        assert abs(float(u.mean()) - 0.5) < 0.02 and abs(float(u.var()) - 1 / 12) < 0.01
+        assert abs(float(torch.corrcoef(torch.stack([u[:-1], u[1:]]))[0, 1])) < 0.05   # neighbouring rays: unrelated draws
+
+
 def test_graphed_trainer_keeps_its_graph_when_the_budget_moves(hiplib):
     """The sample budget is a device scalar of the captured step: mean_count moving inside the capacity window costs no capture,
     leaving it costs one."""

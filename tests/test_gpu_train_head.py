@@ -302,14 +302,18 @@ def test_training_steps_equal_the_operator_path(hiplib, monkeypatch):
 
 
 def test_training_step_launch_count(hiplib, monkeypatch):
-    """An eager training step is <= 40 kernel launches: counted with the profiler's kernel events."""
+    """An eager training step is <= 32 kernel launches in the product configuration (VERDICT r2 item 1 asked for <= 40; round 2:
+    133): counted with the profiler's kernel events, on a step with the running-average budget (the one-launch marcher)."""
     from radnerf.train import SyntheticTrainStream, Trainer
     monkeypatch.setenv("RN_TRAIN_HEAD", "fused")
+    monkeypatch.setenv("RN_TRAIN_NOISE", "hash")
     scene = _scene(64)
     stream = SyntheticTrainStream(scene, n_rays=1024, seed=4)
     trainer = Trainer(scene.model, scene.opt, update_extra_interval=0)
     for _ in range(3):
         trainer.step(stream.batch())
+    scene.model.mean_count = 12000                           # as after the first 16 steps: the budgeted step
+    trainer.step(stream.batch())
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
@@ -319,7 +323,8 @@ def test_training_step_launch_count(hiplib, monkeypatch):
     kernels = [e for e in prof.events() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
     names = [e.name for e in kernels]
     print(len(names), "device activities:", sorted(set(names)))
-    assert 0 < len(names) <= 40, names
+    assert any("k_march_train_step" in n for n in names), names
+    assert 0 < len(names) <= 32, names
 
 
 def test_batch_gather_equals_indexing(hiplib):
