@@ -7,7 +7,10 @@ export TMPDIR=/tmp
 cd "$R"
 run() { local out="$1"; shift; timeout -k 10 400 "$@" > "$O/$out" 2> "$O/${out%.json}.err" || { echo "FAILED: $*"; tail -5 "$O/${out%.json}.err"; exit 1; }; }
 if [ "${PART:-A}" = "A" ]; then
+if [ "${SKIP_TESTS:-0}" != 1 ]; then
 timeout -k 10 1000 python -m pytest tests -q -m gpu > "$O/pytest_gpu.log" 2>&1; rc=$?; tail -3 "$O/pytest_gpu.log"; [ $rc -eq 0 ] || exit $rc
+fi
+[ "${ONLY_TESTS:-0}" = 1 ] && exit 0
 timeout -k 10 300 python __graft_entry__.py smoke > "$O/smoke.log" 2>&1 || { tail -5 "$O/smoke.log"; exit 1; }; tail -2 "$O/smoke.log"
 run bench_hash19_f32.json python bench.py
 run bench_hash19_f32_driver_shape.json python bench.py --steps 20 --warmup 5
