@@ -16,6 +16,8 @@ tests/test_gpu_fused.py).
 import ctypes as C
 
 import numpy as np
+import os
+
 import torch
 
 import radnerf_hip as hip
@@ -469,7 +471,7 @@ def render_frame(model, rays_o, rays_d, enc_a, ind_code, eye, bg_coords, poses, 
     h.deltas = st.samples.data_ptr() + N * 6 * 4
     h.sigmas, h.rgbs = st.sigmas.data_ptr(), st.rgbs.data_ptr()
     h.state, h.block_counts = st.state.data_ptr(), st.block_counts.data_ptr()
-    h.live_slots = st.live_slots.data_ptr() if getattr(model.opt, "live_list", True) else None
+    h.live_slots = st.live_slots.data_ptr() if (getattr(model.opt, "live_list", True) and os.environ.get("RN_LIVE_LIST", "1") != "0") else None
     # image width, if the caller said the rays are the row-major pixels of an image (SyntheticScene does): the loop then
     # walks the rays in 8 x 8 pixel blocks (more shared grid rows per wave; no pixel changes)
     h.order_w = int(getattr(model, "ray_order_width", 0) or 0)
