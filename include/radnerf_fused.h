@@ -140,7 +140,8 @@ int rn_head_iterate(const rn_head_t *h, const rn_grid_t *grid_xyz, const rn_grid
  *                          frame in state[RN_HEAD_ST_UNFINISHED] when the loop was still active) and leaves both live-sample
  *                          counters (state[6], state[14]) at zero, which rn_frame_begin relies on;
  *   RN_LOOP_COOP           compositor + compaction (+ next march) of an iteration run as ONE launch with a grid-wide barrier inside
- *                          (2 launches per iteration instead of 3; same results; measured 2 % slower than the split form).  The launch
+ *                          (2 launches per iteration instead of 3; same results; slower than the split form: 2 % with a plain launch, 15 % with the
+ *                          cooperative launch it now uses for the residency guarantee).  The launch
  *                          needs its <= 512 workgroups of 256 threads resident together: it is a COOPERATIVE launch
  *                          (hipLaunchCooperativeKernel), which the runtime places whole or refuses -- a refusal comes back as
  *                          RN_ERR_INVALID_ARG and the caller falls back to the split loop.  Should a workgroup ever give up waiting
