@@ -56,6 +56,16 @@ __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
 __device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
     return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
 }
+// The same for coordinates < 256 (every occupancy grid of this repo: H = 128): expand_bits()' first step only moves bits 8 and 9.
+__device__ __forceinline__ uint32_t expand_bits8(uint32_t v) {
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D_8(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits8(x) | (expand_bits8(y) << 1) | (expand_bits8(z) << 2);
+}
 // raymarching.cu:73-81
 __device__ __forceinline__ uint32_t morton3D_invert(uint32_t x) {
     x = x & 0x49249249u;

@@ -74,7 +74,7 @@ struct Dda {
             nx = (int)clampf((x * rmb1 + 1) * half_h1, 0.0f, top1);
             ny = (int)clampf((y * rmb1 + 1) * half_h1, 0.0f, top1);
             nz = (int)clampf((z * rmb1 + 1) * half_h1, 0.0f, top1);
-            return morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+            return morton3D_8((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);    // one_cascade implies H <= 256
         }
         int level = 0;
         if (Cf > 1.0f) {  // wave-uniform
