@@ -397,6 +397,51 @@ def test_grid_encoder_module_uses_planned_path_and_matches_oracle(po, hiplib, rn
     assert np.array_equal(y.cpu().numpy(), e_out.transpose(1, 0, 2).reshape(B, -1))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_grid_rows_equal_the_transposition_pass_at_full_size(hiplib, dtype):
+    """B = 2^22 + 777 samples (the size the lookup is benchmarked at, one full chunk and an odd tail chunk), hash T = 2^19: the
+    [B, L*C] rows written by the last level launch are, bit for bit, the rows the transposition pass builds (that path is
+    pinned by the oracle at the sizes the oracle finishes in seconds), and rows of the level-major output transposed on the host."""
+    import ctypes as C_
+    import os
+    import radnerf_hip as hip
+    from gridencoder.encoder import level_offsets
+    D, C, L, log2T = 3, 2, 16, 19
+    B = (1 << 22) + 777
+    scale = float(np.exp2(np.log2(2048 / 16) / (L - 1)))
+    offsets = level_offsets(D, L, scale, 16, log2T, False)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    table = (torch.rand(int(offsets[-1]), C, device="cuda", generator=g) - 0.5)
+    if dtype == "f16":
+        table = table.half()
+    x = torch.rand(B, D, device="cuda", generator=g)
+    x[:5] = 1.5                                                    # outside [0, 1]: zero rows
+    S = float(np.log2(scale))
+    oh = (C_.c_int32 * len(offsets))(*[int(v) for v in offsets])
+    od = torch.from_numpy(offsets).cuda()
+    did = hip.RN_F16 if dtype == "f16" else hip.RN_F32
+    ws = torch.empty(hip.workspace_bytes_grid(B, L, C, did), dtype=torch.uint8, device="cuda")
+
+    def run(layout, rows):
+        out = torch.full((L, B, C) if layout == 0 else (B, L * C), float("nan"), device="cuda", dtype=table.dtype)
+        if rows is not None:
+            os.environ["RN_GRID_ROWS"] = rows
+        try:
+            hip.call("rn_grid_encode_forward_ws", hip.ptr(x), hip.ptr(table), hip.ptr(od, torch.int32), oh, hip.ptr(out), B, D, C, L, S, 16, None,
+                     0, 0, 0, did, layout, hip.ptr(ws), ws.numel(), hip.stream())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("RN_GRID_ROWS", None)
+        return out
+    rows = run(1, None)
+    transposed = run(1, "0")
+    assert torch.equal(rows, transposed)
+    del transposed
+    lbc = run(0, None)
+    assert torch.equal(rows.view(B, L, C), lbc.permute(1, 0, 2))
+    assert not torch.isnan(rows).any() and float(rows[:5].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("gridtype,log2T", [("hash", 19), ("tiled", 16)])
 def test_grid_encoder_module_folds_the_bound_and_writes_rows_without_a_transposition(hiplib, gridtype, log2T):
     """GridEncoder.forward with no gradient wanted = ONE library call (rn_grid_encode_forward_bound: grid.py:149's normalisation
