@@ -391,6 +391,10 @@ class GraphedTrainer(Trainer):
             if isinstance(self._static.get("index"), (list, tuple)):     # a Python list would be uploaded inside the capture
                 self._static_index = list(self._static["index"])
                 self._static["index"] = torch.tensor(self._static["index"], dtype=torch.long, device=self._counter.device)
+        from raymarching.ops import step_marcher_prepare, step_marcher_supported
+        n_rays = int(self._static["rays_o"].reshape(-1, 3).shape[0])
+        if step_marcher_supported(n_rays, self._counter.device):
+            step_marcher_prepare(n_rays, self._counter.device)       # persistent state: must not be born inside the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)

@@ -224,8 +224,18 @@ def _step_state(N, device):
     key = (device.index, int(N))
     st = _STEP_STATE.get(key)
     if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            # memory allocated while capturing belongs to the graph and its zero-fill would be replayed: the launch epoch (and with
+            # it the hash jitter) would restart on every replay
+            raise RuntimeError("march_rays_train_step: create the launch state before capturing (raymarching.ops.step_marcher_prepare)")
         st = _STEP_STATE[key] = torch.zeros(int(hip._lib.rn_march_rays_train_step_state(int(N))) // 4, dtype=torch.int32, device=device)
     return st
+
+
+def step_marcher_prepare(N, device):
+    """Allocate the persistent launch state of march_rays_train_step for N rays on `device` (call before capturing a step that
+    uses it in a graph; eager callers need not bother)."""
+    _step_state(N, torch.device(device) if not isinstance(device, torch.device) else device)
 
 
 def step_marcher_supported(N, device):

@@ -360,6 +360,32 @@ def test_step_marcher_hash_jitter_is_a_new_uniform_draw_per_launch(hiplib):
         assert abs(float(torch.corrcoef(torch.stack([u[:-1], u[1:]]))[0, 1])) < 0.05   # neighbouring rays: unrelated draws
 
 
+def test_replayed_steps_draw_new_jitter(hiplib, monkeypatch):
+    """Product configuration (RN_TRAIN_NOISE=hash) under GraphedTrainer: the marcher's launch epoch lives OUTSIDE the captured graph
+    (allocated before the capture), so every replay advances it and draws new jitter -- a state born inside the capture would be
+    re-zeroed by every replay and the same jitter would come back each step."""
+    from raymarching import ops
+    from radnerf.train import GraphedTrainer, SyntheticTrainStream
+    monkeypatch.setenv("RN_TRAIN_NOISE", "hash")
+    scene = _scene(64, torso=False, smooth_lips=False)
+    stream = SyntheticTrainStream(scene, n_rays=2048, seed=3)
+    m = scene.model
+    trainer = GraphedTrainer(m, scene.opt, update_extra_interval=0)
+    for _ in range(3):
+        trainer.step(stream.batch())
+    m.mean_count = 30000
+    batch = stream.batch()
+    epochs, counts = [], []
+    for _ in range(6):
+        trainer.step(batch)                                        # the SAME rays every time: only the jitter can move the count
+        epochs.append(int(ops._STEP_STATE[(m.density_bitfield.device.index, 2048)][0]))
+        counts.append(int(m.step_counter[(m.local_step - 1) % 16, 0]))
+    assert trainer.captures == 1 and trainer.replays == 6
+    assert epochs == list(range(epochs[0], epochs[0] + 6)), epochs
+    assert int(ops._STEP_STATE[(m.density_bitfield.device.index, 2048)][1]) == 0      # no exchange timed out
+    assert len(set(counts)) > 1, counts
+
+
 def test_graphed_trainer_keeps_its_graph_when_the_budget_moves(hiplib):
     """The sample budget is a device scalar of the captured step: mean_count moving inside the capacity window costs no capture,
     leaving it costs one."""
