@@ -285,6 +285,15 @@ typedef struct {
 int rn_audio_encode_windows_backward(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes,
                                      const float *grad_enc, const rn_audio_grads_t *grads, float *grad_codes,
                                      rn_stream_t stream);
+/* The pair a training step uses: the forward keeps every AudioNet layer's output of every frame in `acts`
+ * (rn_audio_train_acts_floats(n, has_att) floats), the backward starts from them instead of running the forward again
+ * (five weight stagings and layer passes of a latency-bound kernel).  Same results as the pair above, bit for bit. */
+size_t rn_audio_train_acts_floats(uint32_t n, int has_att);
+int rn_audio_encode_windows_train(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, float *workspace,
+                                  float *acts, rn_stream_t stream);
+int rn_audio_encode_windows_backward_acts(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes,
+                                          const float *grad_enc, const rn_audio_grads_t *grads, float *grad_codes,
+                                          const float *acts, rn_stream_t stream);
 /* The same for n consecutive frames (first + i) mod T of a feature stream feats [T, dim_in, 16]: the windows are cut on
  * the device exactly as get_audio_features(att_mode=2) does (nerf/utils.py:56-72: frames index-4 .. index+3, zero rows
  * outside the stream).  Needs T >= 8 and has_att. */

@@ -114,7 +114,15 @@ struct Source {
 };
 
 // AudioNet on ONE frame per workgroup: blockIdx.x = window * frames_per_window + t; codes [n * frames][dim_aud]
-__global__ void __launch_bounds__(kAudioThreads) k_audio_frames(AudioW w, Source src, float *__restrict__ codes) {
+// acts (nullable; the training forward): every layer's output of the frame, [n * frames][kActs] = y1 [32][8] | y2 [32][4] |
+// y3 [64][2] | y4 [64] | y5 [64], for k_audio_frames_bwd to start from instead of running the forward again
+constexpr int kActs = 32 * 8 + 32 * 4 + 64 * 2 + 64 + 64;
+__device__ __forceinline__ void keep_acts(float *acts, int at, const float *buf, int n) {   // call after the layer's barrier
+    if (!acts) return;
+    for (int i = threadIdx.x; i < n; i += kAudioThreads) acts[(size_t)blockIdx.x * kActs + at + i] = buf[i];
+}
+
+__global__ void __launch_bounds__(kAudioThreads) k_audio_frames(AudioW w, Source src, float *__restrict__ codes, float *__restrict__ acts) {
     __shared__ float wts0[kMaxWeights], wts1[kMaxWeights];  // weights of the layer computing / of the next one
     __shared__ float bufA[kMaxDimIn * kWin];  // ping
     __shared__ float bufB[32 * 8];            // pong (largest: conv1 output)
@@ -144,22 +152,27 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_frames(AudioW w, Source
     conv3(bufA, bufB, wts0, w.conv_b[0], 1, cin0, 32, 16, 2);
     pre.store(wts1, 32 * 32 * 3);
     __syncthreads();
+    keep_acts(acts, 0, bufB, 32 * 8);
     pre.load(w.conv_w[2], 64 * 32 * 3);
     conv3(bufB, bufA, wts1, w.conv_b[1], 1, 32, 32, 8, 2);
     pre.store(wts0, 64 * 32 * 3);
     __syncthreads();
+    keep_acts(acts, 256, bufA, 32 * 4);
     pre.load(w.conv_w[3], 64 * 64 * 3);
     conv3(bufA, bufB, wts0, w.conv_b[2], 1, 32, 64, 4, 2);
     pre.store(wts1, 64 * 64 * 3);
     __syncthreads();
+    keep_acts(acts, 384, bufB, 64 * 2);
     pre.load(w.fc_w[0], 64 * 64);
     conv3(bufB, bufA, wts1, w.conv_b[3], 1, 64, 64, 2, 2);  // -> [64][1]
     pre.store(wts0, 64 * 64);
     __syncthreads();
+    keep_acts(acts, 512, bufA, 64);
     pre.load(w.fc_w[1], A * 64);
     linear(bufA, bufB, wts0, w.fc_b[0], 1, 64, 64, true);
     pre.store(wts1, A * 64);
     __syncthreads();
+    keep_acts(acts, 576, bufB, 64);
     linear(bufB, codes + (size_t)blockIdx.x * A, wts1, w.fc_b[1], 1, 64, A, false);
 }
 
@@ -374,7 +387,8 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_attend_bwd(AudioW w, Au
 }
 
 // AudioNet backward, one frame per workgroup: grad_codes [n * frames][A] -> weight gradients
-__global__ void __launch_bounds__(kAudioThreads) k_audio_frames_bwd(AudioW w, AudioG g, Source src, const float *__restrict__ grad_codes) {
+__global__ void __launch_bounds__(kAudioThreads) k_audio_frames_bwd(AudioW w, AudioG g, Source src, const float *__restrict__ grad_codes,
+                                                                    const float *__restrict__ acts) {
     __shared__ float wts[kMaxWeights];
     __shared__ float x0[kMaxDimIn * kWin], y1[32 * 8], y2[32 * 4], y3[64 * 2], y4[64], y5[64];
     __shared__ float ga[32 * 8], gb_[32 * 8];
@@ -392,6 +406,18 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_frames_bwd(AudioW w, Au
         }
         x0[i] = v;
     }
+    if (acts) {   // the forward kept every layer's output (k_audio_frames): five weight stagings and layer passes less
+        const float *a = acts + (size_t)blockIdx.x * kActs;
+        for (int i = threadIdx.x; i < kActs; i += kAudioThreads) {
+            const float v = a[i];
+            if (i < 256) y1[i] = v;
+            else if (i < 384) y2[i - 256] = v;
+            else if (i < 512) y3[i - 384] = v;
+            else if (i < 576) y4[i - 512] = v;
+            else y5[i - 576] = v;
+        }
+        __syncthreads();
+    } else {
     // forward with every layer kept (same helpers, same order of operations as k_audio_frames)
     stage_weights(wts, w.conv_w[0], 32 * cin0 * 3); __syncthreads();
     conv3(x0, y1, wts, w.conv_b[0], 1, cin0, 32, 16, 2); __syncthreads();
@@ -403,6 +429,7 @@ __global__ void __launch_bounds__(kAudioThreads) k_audio_frames_bwd(AudioW w, Au
     conv3(y3, y4, wts, w.conv_b[3], 1, 64, 64, 2, 2); __syncthreads();
     stage_weights(wts, w.fc_w[0], 64 * 64); __syncthreads();
     linear(y4, y5, wts, w.fc_b[0], 1, 64, 64, true); __syncthreads();
+    }
     // backward
     for (int i = threadIdx.x; i < A; i += kAudioThreads) ga[i] = grad_codes[(size_t)blockIdx.x * A + i];
     stage_weights(wts, w.fc_w[1], A * 64); __syncthreads();
@@ -448,14 +475,14 @@ using namespace rn;
 extern "C" {
 
 static int launch_audio(const rn_audio_weights_t *w, const Source &src, uint32_t n, float *enc, float *workspace, hipStream_t s,
-                        const char *what) {
+                        const char *what, float *acts = nullptr) {
     const AudioW a = audio_w(w);
     if (!a.has_att) {  // one frame per window: the frame code is the result
-        hipLaunchKernelGGL(k_audio_frames, dim3(n), dim3(kAudioThreads), 0, s, a, src, enc);
+        hipLaunchKernelGGL(k_audio_frames, dim3(n), dim3(kAudioThreads), 0, s, a, src, enc, acts);
         return check_launch(what);
     }
     RN_REQUIRE(workspace, "%s: workspace of n * 8 * dim_aud floats is required", what);
-    hipLaunchKernelGGL(k_audio_frames, dim3(n * kSeq), dim3(kAudioThreads), 0, s, a, src, workspace);
+    hipLaunchKernelGGL(k_audio_frames, dim3(n * kSeq), dim3(kAudioThreads), 0, s, a, src, workspace, acts);
     hipLaunchKernelGGL(k_audio_attend, dim3(n), dim3(kAudioThreads), 0, s, a, workspace, enc);
     return check_launch(what);
 }
@@ -477,8 +504,33 @@ int rn_audio_encode_stream(const rn_audio_weights_t *w, const float *feats, uint
     return launch_audio(w, Source{feats, T, first, 1}, n, enc, workspace, as_stream(stream), "audio_encode_stream");
 }
 
+size_t rn_audio_train_acts_floats(uint32_t n, int has_att) { return (size_t)n * (has_att ? kSeq : 1) * kActs; }
+
+int rn_audio_encode_windows_train(const rn_audio_weights_t *w, const float *auds, uint32_t n, float *enc, float *workspace, float *acts,
+                                  rn_stream_t stream) {
+    if (n == 0) return RN_OK;
+    if (int rc = check_audio(w)) return rc;
+    RN_REQUIRE(auds && enc && acts, "audio_encode_windows_train: null pointer");
+    return launch_audio(w, Source{auds, 0u, 0u, 0}, n, enc, workspace, as_stream(stream), "audio_encode_windows_train", acts);
+}
+
+static int audio_backward(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes, const float *grad_enc,
+                          const rn_audio_grads_t *grads, float *grad_codes, const float *acts, rn_stream_t stream);
+
 int rn_audio_encode_windows_backward(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes,
                                      const float *grad_enc, const rn_audio_grads_t *grads, float *grad_codes, rn_stream_t stream) {
+    return audio_backward(w, auds, n, codes, grad_enc, grads, grad_codes, nullptr, stream);
+}
+
+int rn_audio_encode_windows_backward_acts(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes,
+                                          const float *grad_enc, const rn_audio_grads_t *grads, float *grad_codes, const float *acts,
+                                          rn_stream_t stream) {
+    RN_REQUIRE(acts, "audio_encode_windows_backward_acts: the activations kept by rn_audio_encode_windows_train are required");
+    return audio_backward(w, auds, n, codes, grad_enc, grads, grad_codes, acts, stream);
+}
+
+static int audio_backward(const rn_audio_weights_t *w, const float *auds, uint32_t n, const float *codes, const float *grad_enc,
+                          const rn_audio_grads_t *grads, float *grad_codes, const float *acts, rn_stream_t stream) {
     if (n == 0) return RN_OK;
     if (int rc = check_audio(w)) return rc;
     RN_REQUIRE(auds && grad_enc && grads, "audio_encode_windows_backward: null pointer");
@@ -489,7 +541,7 @@ int rn_audio_encode_windows_backward(const rn_audio_weights_t *w, const float *a
     const Source src{auds, 0u, 0u, 0};
     hipStream_t s = as_stream(stream);
     if (!a.has_att) {
-        hipLaunchKernelGGL(k_audio_frames_bwd, dim3(n), dim3(kAudioThreads), 0, s, a, g, src, grad_enc);
+        hipLaunchKernelGGL(k_audio_frames_bwd, dim3(n), dim3(kAudioThreads), 0, s, a, g, src, grad_enc, acts);
         return check_launch("audio_encode_windows_backward");
     }
     RN_REQUIRE(codes && grad_codes, "audio_encode_windows_backward: the forward's per-frame codes and n * 8 * dim_aud floats of scratch are required");
@@ -497,7 +549,7 @@ int rn_audio_encode_windows_backward(const rn_audio_weights_t *w, const float *a
     g.att_fc_w = grads->att_fc_w; g.att_fc_b = grads->att_fc_b;
     RN_REQUIRE(g.att_fc_w && g.att_fc_b, "audio backward: null AudioAttNet gradient buffer");
     hipLaunchKernelGGL(k_audio_attend_bwd, dim3(n), dim3(kAudioThreads), 0, s, a, g, codes, grad_enc, grad_codes);
-    hipLaunchKernelGGL(k_audio_frames_bwd, dim3(n * kSeq), dim3(kAudioThreads), 0, s, a, g, src, grad_codes);
+    hipLaunchKernelGGL(k_audio_frames_bwd, dim3(n * kSeq), dim3(kAudioThreads), 0, s, a, g, src, grad_codes, acts);
     return check_launch("audio_encode_windows_backward");
 }
 

@@ -28,6 +28,8 @@ class AudioGradsT(C.Structure):
 _SIGS = {
     "rn_audio_encode_windows": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, _ptr],
     "rn_audio_encode_windows_backward": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, C.POINTER(AudioGradsT), _ptr, _ptr],
+    "rn_audio_encode_windows_train": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, _ptr, _ptr],
+    "rn_audio_encode_windows_backward_acts": [C.POINTER(AudioWeightsT), _ptr, _u32, _ptr, _ptr, C.POINTER(AudioGradsT), _ptr, _ptr, _ptr],
     "rn_audio_encode_stream": [C.POINTER(AudioWeightsT), _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "rn_audio_smooth": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr],
     "rn_audio_smooth_seq": [_ptr, _u32, _u32, C.c_float, _ptr, C.c_int, _ptr, _ptr],
@@ -35,10 +37,12 @@ _SIGS = {
 for _n, _a in _SIGS.items():
     getattr(_lib, _n).argtypes = _a
     getattr(_lib, _n).restype = C.c_int
+_lib.rn_audio_train_acts_floats.argtypes = [_u32, C.c_int]
+_lib.rn_audio_train_acts_floats.restype = C.c_size_t
 
 
 def exported_symbols():
-    return sorted(_SIGS)
+    return sorted(list(_SIGS) + ["rn_audio_train_acts_floats"])
 
 
 def supported(model):
@@ -123,15 +127,17 @@ class _EncodeWindows(torch.autograd.Function):
         enc = torch.empty(n, model.audio_dim, dtype=torch.float32, device=auds.device)
         codes = torch.empty(n * 8, model.audio_dim, dtype=torch.float32, device=auds.device)
         w, keep = _weights(model)
-        hip.call("rn_audio_encode_windows", C.byref(w), hip.ptr(auds), n, hip.ptr(enc), hip.ptr(codes), hip.stream())
+        # the forward keeps every layer's output per frame; the backward starts from them (no second forward inside it)
+        acts = torch.empty(int(_lib.rn_audio_train_acts_floats(n, 1 if model.att > 0 else 0)), dtype=torch.float32, device=auds.device)
+        hip.call("rn_audio_encode_windows_train", C.byref(w), hip.ptr(auds), n, hip.ptr(enc), hip.ptr(codes), hip.ptr(acts), hip.stream())
         ctx.model = model
-        ctx.save_for_backward(auds, codes)
+        ctx.save_for_backward(auds, codes, acts)
         return enc
 
     @staticmethod
     def backward(ctx, grad_enc):
         model = ctx.model
-        auds, codes = ctx.saved_tensors
+        auds, codes, acts = ctx.saved_tensors
         params = _parameters(model)
         sizes = [p.numel() for p in params]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=auds.device)      # one memset for all gradient buffers
@@ -152,8 +158,8 @@ class _EncodeWindows(torch.autograd.Function):
         w, keep = _weights(model)
         ge = grad_enc.contiguous().float()
         scratch = torch.empty_like(codes)
-        hip.call("rn_audio_encode_windows_backward", C.byref(w), hip.ptr(auds), auds.shape[0], hip.ptr(codes), hip.ptr(ge), C.byref(g),
-                 hip.ptr(scratch), hip.stream())
+        hip.call("rn_audio_encode_windows_backward_acts", C.byref(w), hip.ptr(auds), auds.shape[0], hip.ptr(codes), hip.ptr(ge), C.byref(g),
+                 hip.ptr(scratch), hip.ptr(acts), hip.stream())
         return (None, None, *views)
 
 
